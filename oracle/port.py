@@ -1,0 +1,194 @@
+"""TEST INFRASTRUCTURE ONLY -- ctypes binding of oracle/libmsm_oracle.so, the
+plain-C restatement of libff's multi_exp path (oracle/msm_oracle.c).
+
+Same call surface as oracle/ref.py (the reference itself) so tests can run either.
+Must never be imported by the product package (libff_amd/).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(HERE, "libmsm_oracle.so")
+
+ALT_BN128, BLS12_377, BW6_761 = 0, 1, 2
+G1, G2 = 1, 2
+NAIVE, NAIVE_PLAIN, BOS_COSTER, BDLO12, BDLO12_SIGNED = 0, 1, 2, 3, 4
+FORM_NORMAL, FORM_SPECIAL = 0, 1
+
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", HERE, "libmsm_oracle.so"])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            build()
+        L = ctypes.CDLL(SO_PATH)
+        L.orc_signed_digit.restype = ctypes.c_long
+        L.orc_digit.restype = ctypes.c_long
+        for f in ("orc_log2", "orc_pippenger_optimal_c", "orc_bdlo12_signed_optimal_c"):
+            getattr(L, f).restype = ctypes.c_size_t
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+
+
+def _u64(a):
+    return np.ascontiguousarray(a, dtype=np.uint64)
+
+
+def sizes(curve, group):
+    out = (ctypes.c_size_t * 4)()
+    assert lib().orc_sizes(curve, group, out) == 0
+    return {"fr_bytes": out[0], "g_bytes": out[1], "coord_bytes": out[2], "fr_bits": out[3]}
+
+
+def scalars_sha512(curve, start, n):
+    s = sizes(curve, G1)
+    out = np.zeros((n, s["fr_bytes"] // 8), dtype=np.uint64)
+    assert lib().orc_scalars_sha512(curve, ctypes.c_uint64(start), ctypes.c_size_t(n), _p(out)) == 0
+    return out
+
+
+def bases_seq(curve, group, n, first=0):
+    s = sizes(curve, group)
+    out = np.zeros((n, s["g_bytes"] // 8), dtype=np.uint64)
+    assert lib().orc_bases_seq(curve, group, ctypes.c_uint64(first), ctypes.c_size_t(n), _p(out)) == 0
+    return out
+
+
+def bases_r32(curve, group, n):
+    s = sizes(curve, group)
+    out = np.zeros((n, s["g_bytes"] // 8), dtype=np.uint64)
+    assert lib().orc_bases_r32(curve, group, ctypes.c_size_t(n), _p(out)) == 0
+    return out
+
+
+def multi_exp(curve, group, bases, scalars, method=BDLO12_SIGNED, form=FORM_SPECIAL,
+              chunks=1, filter_one_zero=False, omp=False):
+    s = sizes(curve, group)
+    n = bases.shape[0]
+    assert scalars.shape[0] == n
+    bases, scalars = _u64(bases), _u64(scalars)
+    out = np.zeros(s["g_bytes"] // 8, dtype=np.uint64)
+    if omp:
+        rc = lib().orc_multi_exp_omp(curve, group, method, form, ctypes.c_size_t(n), _p(bases),
+                                     _p(scalars), ctypes.c_size_t(chunks), _p(out))
+    else:
+        rc = lib().orc_multi_exp(curve, group, method, form, int(filter_one_zero), ctypes.c_size_t(n),
+                                 _p(bases), _p(scalars), ctypes.c_size_t(chunks), _p(out))
+    assert rc == 0, rc
+    return out
+
+
+def group_op(curve, group, op, a, b=None):
+    a = _u64(a)
+    b = _u64(b) if b is not None else None
+    out = np.zeros_like(a)
+    rc = lib().orc_group_op(curve, group, op, _p(a), _p(b), _p(out))
+    if op == 6:
+        return rc
+    assert rc == 0
+    return out
+
+
+def fq_op(curve, group, op, a, b=None):
+    a = _u64(a)
+    b = _u64(b) if b is not None else None
+    out = np.zeros_like(a)
+    assert lib().orc_fq_op(curve, group, op, _p(a), _p(b), _p(out)) == 0
+    return out
+
+
+def scalar_mul(curve, group, base, scalar):
+    base, scalar = _u64(base), _u64(scalar)
+    out = np.zeros_like(base)
+    assert lib().orc_scalar_mul(curve, group, _p(base), _p(scalar), _p(out)) == 0
+    return out
+
+
+def _rowwise(fn, curve, arr):
+    arr = _u64(arr)
+    out = np.zeros_like(arr)
+    fi, fo = arr.reshape(-1, arr.shape[-1]), out.reshape(-1, arr.shape[-1])
+    for i in range(fi.shape[0]):
+        assert fn(curve, _p(fi[i]), _p(fo[i])) == 0
+    return out
+
+
+def fr_as_bigint(curve, mont):
+    return _rowwise(lib().orc_fr_as_bigint, curve, mont)
+
+
+def fr_from_bigint(curve, plain):
+    return _rowwise(lib().orc_fr_from_bigint, curve, plain)
+
+
+def signed_digit(curve, plain, c, idx):
+    return int(lib().orc_signed_digit(curve, _p(_u64(plain)), ctypes.c_size_t(c), ctypes.c_size_t(idx)))
+
+
+def digit(curve, plain, c, idx):
+    return int(lib().orc_digit(curve, _p(_u64(plain)), ctypes.c_size_t(c), ctypes.c_size_t(idx)))
+
+
+def group_consts(curve, group):
+    s = sizes(curve, group)
+    one = np.zeros(s["g_bytes"] // 8, dtype=np.uint64)
+    zero = np.zeros(s["g_bytes"] // 8, dtype=np.uint64)
+    assert lib().orc_group_consts(curve, group, _p(one), _p(zero)) == 0
+    return one, zero
+
+
+def batch_to_special(curve, group, elems):
+    elems = _u64(elems).copy()
+    assert lib().orc_batch_to_special(curve, group, ctypes.c_size_t(elems.shape[0]), _p(elems)) == 0
+    return elems
+
+
+def bdlo12_signed_optimal_c(n):
+    return int(lib().orc_bdlo12_signed_optimal_c(ctypes.c_size_t(n)))
+
+
+def pippenger_optimal_c(n):
+    return int(lib().orc_pippenger_optimal_c(ctypes.c_size_t(n)))
+
+
+def ffi_group_write(curve, group, g):
+    s = sizes(curve, group)
+    buf = np.zeros(2 * s["coord_bytes"], dtype=np.uint8)
+    ok = lib().orc_ffi_group_write(curve, group, _p(_u64(g)), _p(buf), ctypes.c_size_t(buf.size))
+    return buf if ok else None
+
+
+def ffi_group_read(curve, group, buf):
+    s = sizes(curve, group)
+    buf = np.ascontiguousarray(buf, dtype=np.uint8)
+    out = np.zeros(s["g_bytes"] // 8, dtype=np.uint64)
+    ok = lib().orc_ffi_group_read(curve, group, _p(buf), ctypes.c_size_t(buf.size), _p(out))
+    return out if ok else None
+
+
+def ffi_fr_write(curve, fr_mont):
+    s = sizes(curve, G1)
+    buf = np.zeros(s["fr_bytes"], dtype=np.uint8)
+    ok = lib().orc_ffi_fr_write(curve, _p(_u64(fr_mont)), _p(buf), ctypes.c_size_t(buf.size))
+    return buf if ok else None
+
+
+def ffi_fr_read(curve, buf):
+    s = sizes(curve, G1)
+    buf = np.ascontiguousarray(buf, dtype=np.uint8)
+    out = np.zeros(s["fr_bytes"] // 8, dtype=np.uint64)
+    ok = lib().orc_ffi_fr_read(curve, _p(buf), ctypes.c_size_t(buf.size), _p(out))
+    return out if ok else None

@@ -1,0 +1,189 @@
+"""TEST INFRASTRUCTURE ONLY -- ctypes binding of oracle/_ref/libff_ref.so.
+
+libff_ref.so is the *reference itself* (clearmatics/libff compiled in place by
+oracle/build_ref.sh through oracle/ref_shim.cpp).  It is used to
+
+  * generate the golden fixtures under tests/golden/ (tests/golden/make_golden.py),
+  * pin the C restatement (oracle/msm_oracle.c) in tests/,
+  * time the reference CPU path for bench.py's ``cpu_baseline`` leg.
+
+It must never be imported by the product package (libff_amd/).
+All arrays are numpy uint64 in libff's in-memory layout (LE limbs, Montgomery).
+"""
+import ctypes
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(HERE, "_ref", "libff_ref.so")
+
+ALT_BN128, BLS12_377, BW6_761 = 0, 1, 2
+G1, G2 = 1, 2
+# libff::multi_exp_method (multiexp.hpp:21-43)
+NAIVE, NAIVE_PLAIN, BOS_COSTER, BDLO12, BDLO12_SIGNED = 0, 1, 2, 3, 4
+FORM_NORMAL, FORM_SPECIAL = 0, 1
+
+_lib = None
+
+
+def available():
+    return os.path.exists(SO_PATH)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = ctypes.CDLL(SO_PATH)
+        L.ref_init.restype = ctypes.c_int
+        L.ref_signed_digit.restype = ctypes.c_long
+        L.ref_digit.restype = ctypes.c_long
+        L.ref_bdlo12_signed_optimal_c.restype = ctypes.c_size_t
+        L.ref_pippenger_optimal_c.restype = ctypes.c_size_t
+        assert L.ref_init() == 0
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+
+
+def sizes(curve, group):
+    out = (ctypes.c_size_t * 4)()
+    assert lib().ref_sizes(curve, group, out) == 0
+    return {"fr_bytes": out[0], "g_bytes": out[1], "coord_bytes": out[2], "fr_bits": out[3]}
+
+
+def scalars_sha512(curve, start, n):
+    s = sizes(curve, G1)
+    out = np.zeros((n, s["fr_bytes"] // 8), dtype=np.uint64)
+    assert lib().ref_scalars_sha512(curve, ctypes.c_uint64(start), ctypes.c_size_t(n), _p(out)) == 0
+    return out
+
+
+def bases_seq(curve, group, n, first=0):
+    s = sizes(curve, group)
+    out = np.zeros((n, s["g_bytes"] // 8), dtype=np.uint64)
+    assert lib().ref_bases_seq(curve, group, ctypes.c_uint64(first), ctypes.c_size_t(n), _p(out)) == 0
+    return out
+
+
+def bases_r32(curve, group, n):
+    s = sizes(curve, group)
+    out = np.zeros((n, s["g_bytes"] // 8), dtype=np.uint64)
+    assert lib().ref_bases_r32(curve, group, ctypes.c_size_t(n), _p(out)) == 0
+    return out
+
+
+def multi_exp(curve, group, bases, scalars, method=BDLO12_SIGNED, form=FORM_SPECIAL,
+              chunks=1, filter_one_zero=False, iters=1, want_time=False):
+    s = sizes(curve, group)
+    n = bases.shape[0]
+    assert scalars.shape[0] == n
+    bases = np.ascontiguousarray(bases, dtype=np.uint64)
+    scalars = np.ascontiguousarray(scalars, dtype=np.uint64)
+    out = np.zeros(s["g_bytes"] // 8, dtype=np.uint64)
+    secs = ctypes.c_double(0.0)
+    rc = lib().ref_multi_exp(curve, group, method, form, int(filter_one_zero),
+                             ctypes.c_size_t(n), _p(bases), _p(scalars),
+                             ctypes.c_size_t(chunks), iters, _p(out), ctypes.byref(secs))
+    assert rc == 0, rc
+    return (out, secs.value) if want_time else out
+
+
+def group_op(curve, group, op, a, b=None):
+    """op: 0 add, 1 mixed_add, 2 dbl, 3 neg, 4 to_affine, 5 operator+, 6 equal"""
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    if b is not None:
+        b = np.ascontiguousarray(b, dtype=np.uint64)
+    out = np.zeros_like(a)
+    rc = lib().ref_group_op(curve, group, op, _p(a), _p(b), _p(out))
+    if op == 6:
+        return rc
+    assert rc == 0
+    return out
+
+
+def fq_op(curve, group, op, a, b=None):
+    """op: 0 mul, 1 sqr, 2 add, 3 sub, 4 neg, 5 inverse (coordinate field of the group)"""
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    if b is not None:
+        b = np.ascontiguousarray(b, dtype=np.uint64)
+    out = np.zeros_like(a)
+    assert lib().ref_fq_op(curve, group, op, _p(a), _p(b), _p(out)) == 0
+    return out
+
+
+def scalar_mul(curve, group, base, scalar):
+    base = np.ascontiguousarray(base, dtype=np.uint64)
+    scalar = np.ascontiguousarray(scalar, dtype=np.uint64)
+    out = np.zeros_like(base)
+    assert lib().ref_scalar_mul(curve, group, _p(base), _p(scalar), _p(out)) == 0
+    return out
+
+
+def fr_as_bigint(curve, mont):
+    mont = np.ascontiguousarray(mont, dtype=np.uint64)
+    out = np.zeros_like(mont)
+    flat_in = mont.reshape(-1, mont.shape[-1])
+    flat_out = out.reshape(-1, mont.shape[-1])
+    for i in range(flat_in.shape[0]):
+        assert lib().ref_fr_as_bigint(curve, _p(flat_in[i]), _p(flat_out[i])) == 0
+    return out
+
+
+def fr_from_bigint(curve, plain):
+    plain = np.ascontiguousarray(plain, dtype=np.uint64)
+    out = np.zeros_like(plain)
+    flat_in = plain.reshape(-1, plain.shape[-1])
+    flat_out = out.reshape(-1, plain.shape[-1])
+    for i in range(flat_in.shape[0]):
+        assert lib().ref_fr_from_bigint(curve, _p(flat_in[i]), _p(flat_out[i])) == 0
+    return out
+
+
+def signed_digit(curve, plain, c, idx):
+    plain = np.ascontiguousarray(plain, dtype=np.uint64)
+    return int(lib().ref_signed_digit(curve, _p(plain), ctypes.c_size_t(c), ctypes.c_size_t(idx)))
+
+
+def digit(curve, plain, c, idx):
+    plain = np.ascontiguousarray(plain, dtype=np.uint64)
+    return int(lib().ref_digit(curve, _p(plain), ctypes.c_size_t(c), ctypes.c_size_t(idx)))
+
+
+def group_consts(curve, group):
+    s = sizes(curve, group)
+    one = np.zeros(s["g_bytes"] // 8, dtype=np.uint64)
+    zero = np.zeros(s["g_bytes"] // 8, dtype=np.uint64)
+    assert lib().ref_group_consts(curve, group, _p(one), _p(zero)) == 0
+    return one, zero
+
+
+def fr_consts(curve):
+    s = sizes(curve, G1)
+    mod = np.zeros(s["fr_bytes"] // 8, dtype=np.uint64)
+    r2 = np.zeros(s["fr_bytes"] // 8, dtype=np.uint64)
+    inv = ctypes.c_uint64(0)
+    assert lib().ref_fr_consts(curve, _p(mod), _p(r2), ctypes.byref(inv)) == 0
+    return mod, r2, inv.value
+
+
+def bdlo12_signed_optimal_c(n):
+    return int(lib().ref_bdlo12_signed_optimal_c(ctypes.c_size_t(n)))
+
+
+def pippenger_optimal_c(n):
+    return int(lib().ref_pippenger_optimal_c(ctypes.c_size_t(n)))
+
+
+def coord_consts(curve, group, which):
+    """which: 0 prime modulus under the coordinates (plain), 1 coeff_b (Montgomery),
+    2 Fq2 non_residue (Montgomery, Fq2 groups only)."""
+    s = sizes(curve, group)
+    out = np.zeros(s["coord_bytes"] // 8, dtype=np.uint64)
+    rc = lib().ref_coord_consts(curve, group, which, _p(out))
+    if rc != 0:
+        return None
+    return out

@@ -1,0 +1,253 @@
+#!/usr/bin/env python3
+"""Generate the curve-constant tables used by the HIP engine and by the CPU oracle.
+
+Inputs are the public domain parameters of the three curves libff's multi_exp is
+benchmarked on (plain integers; they are cross-checked in tests against the values
+the reference itself reports -- tests/golden/curve_consts.json, produced from
+alt_bn128_init.cpp:43-122,287-297,355-373, bls12_377_init.cpp:60-130,174-176,
+301-335,430-450 and bw6_761_init.cpp:38-117,266-300,368-381 through oracle/ref.py).
+
+Everything derived (R, R^2, -p^-1 mod 2^32/2^64, Montgomery forms) is computed here.
+
+Outputs:
+  libff_amd/csrc/curve_params.h   32-bit-limb constexpr tables for the device code
+  oracle/curve_consts.h           64-bit-limb tables for the C restatement
+"""
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CURVES = {
+    "alt_bn128": dict(
+        id=0,
+        r=0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001,
+        q=0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47,
+        coords="jacobian",
+        g1=dict(deg=1, x=[1], y=[2], b=[3]),
+        g2=dict(
+            deg=2,
+            nr=-1,
+            x=[0x1800DEEF121F1E76426A00665E5C4479674322D4F75EDADD46DEBD5CD992F6ED,
+               0x198E9393920D483A7260BFB731FB5D25F1AA493335A9E71297E485B7AEF312C2],
+            y=[0x12C85EA5DB8C6DEB4AAB71808DCB408FE3D1E7690C43D37B4CE6CC0166FA7DAA,
+               0x090689D0585FF075EC9E99AD690C3395BC4B313370B38EF355ACDADCD122975B],
+            b=[0x2B149D40CEB8AAAE81BE18991BE06AC3B5B4C5E559DBEFA33267E6DC24A138E5,
+               0x009713B03AF0FED4CD2CAFADEED8FDF4A74FA084E52D1852E4A2BD0685C315D2],
+        ),
+    ),
+    "bls12_377": dict(
+        id=1,
+        r=0x12AB655E9A2CA55660B44D1E5C37B00159AA76FED00000010A11800000000001,
+        q=0x1AE3A4617C510EAC63B05C06CA1493B1A22D9F300F5138F1EF3622FBA094800170B5D44300000008508C00000000001,
+        coords="jacobian",
+        g1=dict(
+            deg=1,
+            x=[0x8848DEFE740A67C8FC6225BF87FF5485951E2CAA9D41BB188282C8BD37CB5CD5481512FFCD394EEAB9B16EB21BE9EF],
+            y=[0x1914A69C5102EFF1F674F5D30AFEEC4BD7FB348CA3E52D96D182AD44FB82305C2FE3D3634A9591AFD82DE55559C8EA6],
+            b=[1],
+        ),
+        g2=dict(
+            deg=2,
+            nr=-5,
+            x=[0xB997FEF930828FE1B9E6A1707B8AA508A3DBFD7FE2246499C709226A0A6FEF49F85B3A375363F4F8F6EA3FBD159F8A,
+               0xD6AC33B84947D9845F81A57A136BFA326E915FABC8CD6A57FF133B42D00F62E4E1AF460228CD5184DEAE976FA62596],
+            y=[0x118DD509B2E9A13744A507D515A595DBB7E3B63DF568866473790184BDF83636C94DF2B7A962CB2AF4337F07CB7E622,
+               0x185067C6CA76D992F064A432BD9F9BE832B0CAC2D824D0518F77D39E76C3E146AFB825F2092218D038867D7F337A010],
+            b=[0,
+               0x10222F6DB0FD6F343BD03737460C589DC7B4F91CD5FD889129207B63C6BF8000DD39E5C1CCCCCCD1C9ED9999999999A],
+        ),
+    ),
+    "bw6_761": dict(
+        id=2,
+        r=0x1AE3A4617C510EAC63B05C06CA1493B1A22D9F300F5138F1EF3622FBA094800170B5D44300000008508C00000000001,
+        q=0x122E824FB83CE0AD187C94004FAFF3EB926186A81D14688528275EF8087BE41707BA638E584E91903CEBAFF25B423048689C8ED12F9FD9071DCD3DC73EBFF2E98A116C25667A8F8160CF8AEEAF0A437E6913E6870000082F49D00000000008B,
+        coords="projective",
+        g1=dict(
+            deg=1,
+            x=[0x1075B020EA190C8B277CE98A477BEAEE6A0CFB7551B27F0EE05C54B85F56FC779017FFAC15520AC11DBFCD294C2E746A17A54CE47729B905BD71FA0C9EA097103758F9A280CA27F6750DD0356133E82055928ACA6AF603F4088F3AF66E5B43D],
+            y=[0x58B84E0A6FC574E6FD637B45CC2A420F952589884C9EC61A7348D2A2E573A3265909F1AF7E0DBAC5B8FA1771B5B806CC685D31717A4C55BE3FB90B6FC2CDD49F9DF141B3053253B2B08119CAD0FB93AD1CB2BE0B20D2A1BAFC8F2DB4E95363],
+            b=[-1],
+        ),
+        g2=dict(
+            deg=1,
+            x=[0x110133241D9B816C852A82E69D660F9D61053AAC5A7115F4C06201013890F6D26B41C5DAB3DA268734EC3F1F09FEB58C5BBCAE9AC70E7C7963317A300E1B6BACE6948CB3CD208D700E96EFBC2AD54B06410CF4FE1BF995BA830C194CD025F1C],
+            y=[0x17C3357761369F8179EB10E4B6D2DC26B7CF9ACEC2181C81A78E2753FFE3160A1D86C80B95A59C94C97EB733293FEF64F293DBD2C712B88906C170FFA823003EA96FCD504AFFC758AA2D3A3C5A02A591EC0594F9EAC689EB70A16728C73B61],
+            b=[4],
+        ),
+    ),
+}
+
+
+def limbs(v, n, bits):
+    mask = (1 << bits) - 1
+    return [(v >> (bits * i)) & mask for i in range(n)]
+
+
+def field(p):
+    n64 = (p.bit_length() + 63) // 64
+    R = 1 << (64 * n64)
+    return dict(
+        p=p, n64=n64, n32=2 * n64, bits=p.bit_length(), R=R % p, R2=(R * R) % p,
+        R3=(R * R * R) % p, inv64=(-pow(p, -1, 1 << 64)) % (1 << 64),
+        inv32=(-pow(p, -1, 1 << 32)) % (1 << 32))
+
+
+def on_curve(q, g):
+    deg = g["deg"]
+    if deg == 1:
+        x, y, b = g["x"][0] % q, g["y"][0] % q, g["b"][0] % q
+        return (y * y - x * x * x - b) % q == 0
+    nr = g["nr"] % q
+
+    def mul(a, c):
+        return ((a[0] * c[0] + nr * a[1] * c[1]) % q, (a[0] * c[1] + a[1] * c[0]) % q)
+
+    x, y, b = g["x"], g["y"], g["b"]
+    x3 = mul(mul(x, x), x)
+    y2 = mul(y, y)
+    return all((y2[i] - x3[i] - b[i]) % q == 0 for i in range(2))
+
+
+def c_arr(vals, fmt):
+    return "{" + ", ".join(fmt % v for v in vals) + "}"
+
+
+def emit_device_header():
+    out = []
+    w = out.append
+    w("// GENERATED by tools/gen_params.py -- do not edit.")
+    w("// 32-bit-limb (little-endian limb order) Montgomery constants for the HIP engine.")
+    w("// Field layout matches libff's bigint<n> (bigint.hpp:28-65) reinterpreted as 2n x u32.")
+    w("#pragma once")
+    w("#include <stdint.h>")
+    w("")
+    w("namespace amdmsm {")
+    w("")
+    w("enum curve_id : int { CURVE_ALT_BN128 = 0, CURVE_BLS12_377 = 1, CURVE_BW6_761 = 2 };")
+    w("enum group_id : int { GROUP_G1 = 1, GROUP_G2 = 2 };")
+    w("")
+    done_fields = {}
+
+    def emit_field(name, p):
+        if name in done_fields:
+            return
+        f = field(p)
+        done_fields[name] = f
+        n = f["n32"]
+        w(f"struct {name} {{")
+        w(f"    static constexpr int N = {n};            // 32-bit limbs")
+        w(f"    static constexpr int BITS = {f['bits']};")
+        w(f"    static constexpr uint32_t INV = 0x{f['inv32']:08x}u;   // -p^-1 mod 2^32")
+        for cname, v in (("P", p), ("R", f["R"]), ("R2", f["R2"])):
+            w(f"    static constexpr uint32_t {cname}[{n}] = {c_arr(limbs(v, n, 32), '0x%08xu')};")
+        w("};")
+        w("")
+
+    for cname, c in CURVES.items():
+        emit_field(f"{cname}_fr", c["r"])
+        emit_field(f"{cname}_fq", c["q"])
+    for cname, c in CURVES.items():
+        fq = field(c["q"])
+        for gname in ("g1", "g2"):
+            g = c[gname]
+            assert on_curve(c["q"], g), (cname, gname)
+            deg = g["deg"]
+            n = fq["n32"]
+            w(f"struct {cname}_{gname} {{")
+            w(f"    using fq = {cname}_fq;")
+            w(f"    using fr = {cname}_fr;")
+            w(f"    static constexpr int CURVE = {c['id']};")
+            w(f"    static constexpr int GROUP = {1 if gname == 'g1' else 2};")
+            w(f"    static constexpr int DEG = {deg};           // coordinate field = Fq^DEG")
+            w(f"    static constexpr bool LIBFF_PROJECTIVE = {'true' if c['coords'] == 'projective' else 'false'};"
+              "  // libff in-memory coords are homogeneous projective")
+            if deg == 2:
+                nr = g["nr"] % c["q"]
+                w(f"    static constexpr int NR_SMALL = {g['nr']};     // Fq2 = Fq[u]/(u^2 - NR)")
+                w(f"    static constexpr uint32_t NR_MONT[{n}] = "
+                  f"{c_arr(limbs(nr * fq['R'] % c['q'], n, 32), '0x%08xu')};")
+            for coord in ("x", "y", "b"):
+                vals = []
+                for comp in g[coord]:
+                    vals += limbs((comp % c["q"]) * fq["R"] % c["q"], n, 32)
+                w(f"    static constexpr uint32_t GEN_{coord.upper()}[{n * deg}] = {c_arr(vals, '0x%08xu')};"
+                  if coord != "b" else
+                  f"    static constexpr uint32_t COEFF_B[{n * deg}] = {c_arr(vals, '0x%08xu')};")
+            w("};")
+            w("")
+    w("} // namespace amdmsm")
+    path = os.path.join(ROOT, "libff_amd", "csrc", "curve_params.h")
+    open(path, "w").write("\n".join(out) + "\n")
+    return path
+
+
+def emit_oracle_header():
+    out = []
+    w = out.append
+    w("/* GENERATED by tools/gen_params.py -- do not edit.")
+    w(" * TEST INFRASTRUCTURE: 64-bit-limb curve constants for oracle/msm_oracle.c. */")
+    w("#ifndef ORACLE_CURVE_CONSTS_H")
+    w("#define ORACLE_CURVE_CONSTS_H")
+    w("#include <stdint.h>")
+    w("#define ORC_MAX_LIMBS 12")
+    w("typedef struct {")
+    w("    int n;                      /* 64-bit limbs */")
+    w("    int bits;")
+    w("    uint64_t inv;               /* -p^-1 mod 2^64 */")
+    w("    uint64_t p[ORC_MAX_LIMBS], r[ORC_MAX_LIMBS], r2[ORC_MAX_LIMBS];")
+    w("} orc_field;")
+    w("typedef struct {")
+    w("    int curve, group, deg, projective;")
+    w("    const orc_field *fq, *fr;")
+    w("    uint64_t nr[ORC_MAX_LIMBS];            /* Fq2 non-residue, Montgomery (deg 2) */")
+    w("    uint64_t gen_x[2 * ORC_MAX_LIMBS], gen_y[2 * ORC_MAX_LIMBS], coeff_b[2 * ORC_MAX_LIMBS];")
+    w("} orc_group;")
+    w("")
+    emitted = {}
+
+    def emit_field(name, p):
+        if name in emitted:
+            return
+        f = field(p)
+        emitted[name] = f
+        n = f["n64"]
+        w(f"static const orc_field orc_{name} = {{ {n}, {f['bits']}, 0x{f['inv64']:016x}ull,")
+        for v in (p, f["R"], f["R2"]):
+            w("    " + c_arr(limbs(v, n, 64), "0x%016xull") + ",")
+        w("};")
+
+    for cname, c in CURVES.items():
+        emit_field(f"{cname}_fr", c["r"])
+        emit_field(f"{cname}_fq", c["q"])
+    names = []
+    for cname, c in CURVES.items():
+        fq = field(c["q"])
+        n = fq["n64"]
+        for gi, gname in ((1, "g1"), (2, "g2")):
+            g = c[gname]
+            deg = g["deg"]
+            nr = (g.get("nr", 0) % c["q"]) * fq["R"] % c["q"]
+
+            def mont(vs):
+                o = []
+                for comp in vs:
+                    o += limbs((comp % c["q"]) * fq["R"] % c["q"], n, 64)
+                return o
+
+            w(f"static const orc_group orc_{cname}_{gname} = {{ {c['id']}, {gi}, {deg}, "
+              f"{1 if c['coords'] == 'projective' else 0}, &orc_{cname}_fq, &orc_{cname}_fr,")
+            w("    " + c_arr(limbs(nr, n, 64), "0x%016xull") + ",")
+            for coord in ("x", "y", "b"):
+                w("    " + c_arr(mont(g[coord]), "0x%016xull") + ",")
+            w("};")
+            names.append(f"orc_{cname}_{gname}")
+    w("static const orc_group *const orc_all_groups[] = { " + ", ".join("&" + n for n in names) + " };")
+    w("#endif")
+    path = os.path.join(ROOT, "oracle", "curve_consts.h")
+    open(path, "w").write("\n".join(out) + "\n")
+    return path
+
+
+if __name__ == "__main__":
+    print(emit_device_header())
+    print(emit_oracle_header())
