@@ -1,0 +1,160 @@
+/* amdmsm -- MI355X (gfx950) multi-scalar-multiplication engine: raw C ABI.
+ *
+ * This is the drop-in boundary for libff's multi_exp hot path.  Every entry point
+ * is `extern "C"` with plain pointers and sizes; no C++ or torch types cross it.
+ *
+ * What each entry replaces in the reference (clearmatics/libff):
+ *   amdmsm_multi_exp          libff::multi_exp<G, Fr, multi_exp_method_BDLO12[_signed], Form>
+ *                             multiexp.hpp:63-73, multiexp.tcc:643-688 (and the inner
+ *                             Pippenger bodies :284-380, :563-632)
+ *   amdmsm_multi_exp_filter_one_zero
+ *                             libff::multi_exp_filter_one_zero, multiexp.hpp:78-88,
+ *                             multiexp.tcc:690-757
+ *   amdmsm_batch_to_special   libff::batch_to_special<G>, multiexp.hpp:136-141,
+ *                             multiexp.tcc:949-974
+ *   amdmsm_bdlo12_signed_optimal_c / amdmsm_pippenger_optimal_c
+ *                             multiexp.hpp:53-57, multiexp.tcc:35-40, 637-641
+ *   amdmsm_*_device           the same path for callers whose vectors already live in
+ *                             HBM (proving keys; the benchmark)
+ * The FFI-convention wrappers (big-endian plain affine buffers, bool return) that
+ * extend ffi/ffi.h:19-95 are declared in include/libff_amd_ffi.h.
+ *
+ * Data layout at the boundary = libff's in-memory layout, untouched:
+ *   scalar   Fp_model<n>: n x uint64 limbs, limb 0 least significant, Montgomery form
+ *            (fp.hpp:43).  AMDMSM_SCALARS_PLAIN selects plain bigint<n> instead.
+ *   point    G = (X, Y, Z), each coordinate deg*n limbs Montgomery (Fq2: c0 then c1,
+ *            fp2.hpp:63); Jacobian for alt_bn128 / bls12_377, homogeneous projective for
+ *            bw6_761 -- whatever libff itself uses for the group.
+ *   "compact affine" (device-resident bases): (x, y), 2*deg*n limbs, (0,0) = infinity.
+ *
+ * Errors: every function returns AMDMSM_OK (0) or a negative code; nothing throws and
+ * nothing falls back to a CPU path -- without a gfx950 device the calls fail with
+ * AMDMSM_ERR_NO_DEVICE.
+ */
+#ifndef AMDMSM_H
+#define AMDMSM_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { AMDMSM_CURVE_ALT_BN128 = 0, AMDMSM_CURVE_BLS12_377 = 1, AMDMSM_CURVE_BW6_761 = 2 };
+enum { AMDMSM_G1 = 1, AMDMSM_G2 = 2 };
+/* multi_exp_base_form, multiexp.hpp:45-51 */
+enum { AMDMSM_FORM_NORMAL = 0, AMDMSM_FORM_SPECIAL = 1 };
+/* result coordinates */
+enum {
+    AMDMSM_OUT_JACOBIAN = 0, /* engine-internal Jacobian (partial results to be combined) */
+    AMDMSM_OUT_LIBFF = 1,    /* libff's coordinate system for the group, not normalised */
+    AMDMSM_OUT_AFFINE = 2    /* libff special form: (x, y, 1) or zero = (0, 1, 0) */
+};
+
+enum {
+    AMDMSM_OK = 0,
+    AMDMSM_ERR_NO_DEVICE = -1,
+    AMDMSM_ERR_BAD_ARG = -2,
+    AMDMSM_ERR_UNSUPPORTED = -3,
+    AMDMSM_ERR_HIP = -4,
+    AMDMSM_ERR_TOO_LARGE = -5
+};
+
+typedef struct amdmsm_ctx amdmsm_ctx;
+
+typedef struct amdmsm_opts {
+    int window_bits;   /* c; 0 = engine picks (see amdmsm_plan) */
+    int segment_len;   /* L for the bucket reduction; 0 = auto */
+    int out_form;      /* AMDMSM_OUT_* ; host entry points default to AMDMSM_OUT_LIBFF */
+    int scalars_plain; /* nonzero: scalars are plain bigints, not Montgomery residues */
+    void *stream;      /* hipStream_t to launch on (device entry points); NULL = context stream */
+} amdmsm_opts;
+
+#define AMDMSM_MAX_PHASES 8
+/* phase indices of amdmsm_get_timings */
+enum {
+    AMDMSM_PH_COUNT = 0,   /* recode + histogram + scan */
+    AMDMSM_PH_SCATTER = 1, /* recode + scatter */
+    AMDMSM_PH_ACCUM = 2,   /* bucket accumulation (dominant kernel) */
+    AMDMSM_PH_REDUCE = 3,  /* bucket reduction levels */
+    AMDMSM_PH_FINAL = 4,   /* Horner over windows */
+    AMDMSM_PH_TOTAL = 5
+};
+
+int amdmsm_device_count(void);
+int amdmsm_ctx_create(int device, amdmsm_ctx **out);
+void amdmsm_ctx_destroy(amdmsm_ctx *ctx);
+const char *amdmsm_strerror(int code);
+const char *amdmsm_last_error(const amdmsm_ctx *ctx);
+
+/* out[0] = sizeof(Fr), out[1] = sizeof(G) (X,Y,Z), out[2] = compact affine bytes, out[3] = Fr bits */
+int amdmsm_sizes(int curve, int group, size_t out[4]);
+
+/* window size / round count / bucket count / workspace the engine would use */
+int amdmsm_plan(int curve, int group, size_t n, int window_bits, int *c, int *num_windows,
+                uint32_t *num_buckets, size_t *workspace_bytes);
+
+/* libff's own window heuristics, kept for API parity (multiexp.hpp:53-57) */
+size_t amdmsm_pippenger_optimal_c(size_t num_elements);
+size_t amdmsm_bdlo12_signed_optimal_c(size_t num_elements);
+
+/* ---- host-buffer entry points (what the multi_exp<> shim and the FFI call) ---- */
+int amdmsm_multi_exp(amdmsm_ctx *ctx, int curve, int group,
+                     const void *bases_xyz, size_t base_stride_bytes, int base_form,
+                     const void *scalars, size_t n,
+                     void *out_xyz, const amdmsm_opts *opts);
+
+int amdmsm_multi_exp_filter_one_zero(amdmsm_ctx *ctx, int curve, int group,
+                                     const void *bases_xyz, size_t base_stride_bytes, int base_form,
+                                     const void *scalars, size_t n,
+                                     void *out_xyz, const amdmsm_opts *opts,
+                                     size_t stats[3] /* skipped, ones, other; may be NULL */);
+
+int amdmsm_batch_to_special(amdmsm_ctx *ctx, int curve, int group, void *elems_xyz,
+                            size_t stride_bytes, size_t n);
+
+/* ---- device-resident entry points (all pointers are HBM addresses) ---- */
+int amdmsm_import_bases_device(amdmsm_ctx *ctx, int curve, int group, const void *d_src_xyz,
+                               size_t stride_bytes, int base_form, size_t n, void *d_dst_affine,
+                               void *stream);
+int amdmsm_export_affine_device(amdmsm_ctx *ctx, int curve, int group, const void *d_src_affine,
+                                size_t n, void *d_dst_xyz, void *stream);
+int amdmsm_msm_device(amdmsm_ctx *ctx, int curve, int group, const void *d_bases_affine,
+                      const void *d_scalars, size_t n, void *d_out_xyz, const amdmsm_opts *opts);
+/* sum of k engine-Jacobian partial results (multi-GPU / chunk combination, multiexp.tcc:681-687) */
+int amdmsm_sum_points_device(amdmsm_ctx *ctx, int curve, int group, const void *d_points_jacobian,
+                             int k, int out_form, void *d_out_xyz, void *stream);
+/* synthetic benchmark input: dst[i] = (first + i + 1) * G::one(), compact affine */
+int amdmsm_gen_bases_seq_device(amdmsm_ctx *ctx, int curve, int group, uint64_t first, size_t n,
+                                void *d_dst_affine, void *stream);
+
+/* ---- per-phase device timing (hipEvents on the launch stream) ---- */
+int amdmsm_set_timing(amdmsm_ctx *ctx, int enable);
+/* milliseconds of the most recent amdmsm_msm_device call; synchronises its stream */
+int amdmsm_get_timings(amdmsm_ctx *ctx, float ms[AMDMSM_MAX_PHASES]);
+
+/* ---- parity-test hooks for the primitives (device pointers) ---- */
+int amdmsm_field_op_device(amdmsm_ctx *ctx, int curve, int group, int op, const void *d_a,
+                           const void *d_b, void *d_out, size_t n);
+int amdmsm_group_op_device(amdmsm_ctx *ctx, int curve, int group, int op, const void *d_a,
+                           const void *d_b, void *d_out, size_t n, int out_form);
+int amdmsm_digits_device(amdmsm_ctx *ctx, int curve, int group, const void *d_scalars, size_t n,
+                         int scalars_plain, int c, int num_windows, int32_t *d_out);
+/* throughput probes (2*iters dependent Fq products / iters mixed additions per lane);
+ * *ms receives the kernel time from HIP events on the context stream */
+int amdmsm_mul_bench_device(amdmsm_ctx *ctx, int curve, int group, void *d_inout, size_t nthreads,
+                            int iters, int inline_variant, float *ms);
+int amdmsm_madd_bench_device(amdmsm_ctx *ctx, int curve, int group, const void *d_points_affine,
+                             void *d_out_xyz, size_t nthreads, int iters, int inline_variant, float *ms);
+
+/* thin hipMalloc / hipMemcpy wrappers so non-HIP hosts (ctypes, cgo, JNI) can stage buffers */
+int amdmsm_malloc(amdmsm_ctx *ctx, size_t bytes, void **d_ptr);
+int amdmsm_free(amdmsm_ctx *ctx, void *d_ptr);
+int amdmsm_memcpy_h2d(amdmsm_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
+int amdmsm_memcpy_d2h(amdmsm_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
+int amdmsm_synchronize(amdmsm_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AMDMSM_H */

@@ -1,0 +1,86 @@
+"""Build libff_amd/libamdmsm.so for gfx950 with hipcc (in-tree, no JIT cache).
+
+One translation unit per (curve, group) pair -- msm_group.hip compiled with
+-DAMDMSM_GROUP=... -- plus the host engine; the six device TUs build in parallel.
+Objects are cached under libff_amd/csrc/build/ keyed by source mtimes.
+"""
+import concurrent.futures
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "build")
+INCLUDE = os.path.join(os.path.dirname(HERE), "include")
+SO_PATH = os.path.join(HERE, "libamdmsm.so")
+
+GROUPS = ["alt_bn128_g1", "alt_bn128_g2", "bls12_377_g1", "bls12_377_g2", "bw6_761_g1", "bw6_761_g2"]
+# per-group code-generation policy (see fp.cuh Fp<P, INL> and msm_group.hip):
+#   AMDMSM_HOT_INLINE  inline the Montgomery product inside the bucket-accumulation loop
+#   AMDMSM_BENCH_BOTH  also build the inline variants of the throughput probes
+GROUP_FLAGS = {
+    "alt_bn128_g1": ["-DAMDMSM_HOT_INLINE=1", "-DAMDMSM_BENCH_BOTH=1"],
+}
+ARCH = "gfx950"
+COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-I" + INCLUDE, "-I" + CSRC,
+          "-Wno-unused-result"]
+DEVICE_DEPS = ["msm_group.hip", "fp.cuh", "fp2.cuh", "ec.cuh", "curve_params.h", "group_vtable.h", os.path.join(HERE, "build.py")]
+HOST_DEPS = ["engine.cpp", "group_vtable.h", os.path.join(INCLUDE, "amdmsm.h")]
+
+
+def hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: the amdmsm engine is HIP-only and cannot be built without ROCm")
+    return exe
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d if os.path.isabs(d) else os.path.join(CSRC, d)) > t for d in deps)
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("command failed: %s\n%s\n%s" % (" ".join(cmd), r.stdout[-4000:], r.stderr[-8000:]))
+    return r
+
+
+def build(force=False, verbose=True, jobs=None):
+    os.makedirs(OBJ, exist_ok=True)
+    cc = hipcc()
+    tasks = []
+    objs = []
+    groups = [g for g in os.environ.get("AMDMSM_GROUPS", ",".join(GROUPS)).split(",") if g]
+    for g in groups:
+        if g not in GROUPS:
+            raise RuntimeError(f"unknown group {g!r}")
+        o = os.path.join(OBJ, f"group_{g}.o")
+        objs.append(o)
+        if force or _newer(o, DEVICE_DEPS):
+            tasks.append([cc, *COMMON, "-c", os.path.join(CSRC, "msm_group.hip"),
+                          f"-DAMDMSM_GROUP={g}", f"-DAMDMSM_VT=vt_{g}", *GROUP_FLAGS.get(g, []), "-o", o])
+    eo = os.path.join(OBJ, "engine.o")
+    objs.append(eo)
+    if force or _newer(eo, HOST_DEPS):
+        tasks.append([cc, *COMMON, "-x", "hip", "-c", os.path.join(CSRC, "engine.cpp"), "-o", eo])
+    if tasks:
+        if verbose:
+            print(f"[libff_amd.build] compiling {len(tasks)} translation unit(s) for {ARCH} ...", flush=True)
+        jobs = jobs or min(len(tasks), max(1, (os.cpu_count() or 2) - 1))
+        with concurrent.futures.ThreadPoolExecutor(max_workers=jobs) as ex:
+            list(ex.map(_run, tasks))
+    if tasks or not os.path.exists(SO_PATH):
+        _run([cc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", SO_PATH, *objs])
+        if verbose:
+            print(f"[libff_amd.build] linked {SO_PATH}", flush=True)
+    return SO_PATH
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,203 @@
+// Short-Weierstrass a = 0 group arithmetic in Jacobian coordinates, generic over
+// the coordinate field (Fq or Fq2).  Device-side counterpart of libff's per-curve
+// group classes on the multi_exp path:
+//   jac_madd  <- G::mixed_add   alt_bn128_g1.cpp:208-283 (madd-2007-bl), same ladder of
+//                               special cases: acc==0 -> P; P==0 -> acc; equal -> dbl;
+//                               opposite points fall out of the formula as Z3 = 0.
+//   jac_add   <- G::add         alt_bn128_g1.cpp:149-206 (add-2007-bl); the equality test
+//                               reuses U1,U2,S1,S2 as bls12_377_g1.cpp:121-178 does.
+//   jac_dbl   <- G::dbl         alt_bn128_g1.cpp:285-326 (dbl-2009-l)
+// bw6_761 uses homogeneous projective coordinates in libff (bw6_761_g1.cpp:111-358);
+// the engine works in Jacobian for every curve (the MSM result is a group element,
+// coordinates are not canonical) and converts at the boundary:
+//   (X:Y:Z)_jac  ->  (X*Z : Y : Z^3)_proj        [x = X/Z^2, y = Y/Z^3]
+// Affine points are (x, y) with (0, 0) standing for the point at infinity (never
+// on y^2 = x^3 + b, b != 0).
+#pragma once
+#include "fp2.cuh"
+
+namespace amdmsm {
+
+template <class E>
+struct Aff {
+    E x, y;
+};
+
+template <class E>
+struct Jac {
+    E x, y, z;
+};
+
+template <class E>
+AMDMSM_DEV bool aff_is_inf(const Aff<E>& p) {
+    return el_is_zero(p.x) && el_is_zero(p.y);
+}
+
+template <class E>
+AMDMSM_DEV void jac_set_inf(Jac<E>& p) {   // G::zero() = (0, 1, 0)
+    el_zero(p.x);
+    el_one(p.y);
+    el_zero(p.z);
+}
+
+template <class E>
+AMDMSM_DEV bool jac_is_inf(const Jac<E>& p) {
+    return el_is_zero(p.z);
+}
+
+template <class E>
+AMDMSM_DEV void jac_from_aff(Jac<E>& r, const Aff<E>& p) {
+    if (aff_is_inf(p)) {
+        jac_set_inf(r);
+    } else {
+        r.x = p.x;
+        r.y = p.y;
+        el_one(r.z);
+    }
+}
+
+template <class E>
+AMDMSM_DEV void jac_dbl(Jac<E>& r, const Jac<E>& p) {
+    if (jac_is_inf(p)) {
+        r = p;
+        return;
+    }
+    E A, B, C, D, F, t;
+    el_sqr(A, p.x);          // A = X1^2
+    el_sqr(B, p.y);          // B = Y1^2
+    el_sqr(C, B);            // C = B^2
+    el_add(t, p.x, B);
+    el_sqr(D, t);
+    el_sub(D, D, A);
+    el_sub(D, D, C);
+    el_dbl(D, D);            // D = 2((X1+B)^2 - A - C)
+    el_dbl(t, A);
+    el_add(A, t, A);         // E = 3A   (kept in A)
+    el_sqr(F, A);            // F = E^2
+    el_mul(t, p.y, p.z);     // Y1*Z1 (before X/Y are overwritten)
+    el_dbl(B, D);
+    el_sub(r.x, F, B);       // X3 = F - 2D
+    el_sub(D, D, r.x);
+    el_mul(D, A, D);         // E*(D - X3)
+    el_dbl(C, C);
+    el_dbl(C, C);
+    el_dbl(C, C);            // 8C
+    el_sub(r.y, D, C);       // Y3
+    el_dbl(r.z, t);          // Z3 = 2*Y1*Z1
+}
+
+// acc += P (P affine).  Full special-case ladder.
+template <class E>
+AMDMSM_DEV void jac_madd(Jac<E>& acc, const Aff<E>& p) {
+    if (aff_is_inf(p)) return;
+    if (jac_is_inf(acc)) {
+        acc.x = p.x;
+        acc.y = p.y;
+        el_one(acc.z);
+        return;
+    }
+    E z1z1, u2, s2, h, hh, i4, j, rr, v, t;
+    el_sqr(z1z1, acc.z);
+    el_mul(u2, p.x, z1z1);
+    el_mul(s2, acc.z, z1z1);
+    el_mul(s2, p.y, s2);
+    if (el_eq(u2, acc.x) && el_eq(s2, acc.y)) {
+        jac_dbl(acc, acc);
+        return;
+    }
+    el_sub(h, u2, acc.x);        // H
+    el_sqr(hh, h);               // HH
+    el_dbl(i4, hh);
+    el_dbl(i4, i4);              // I = 4HH
+    el_mul(j, h, i4);            // J
+    el_sub(rr, s2, acc.y);
+    el_dbl(rr, rr);              // r = 2(S2 - Y1)
+    el_mul(v, acc.x, i4);        // V
+    el_mul(t, acc.z, h);
+    el_dbl(acc.z, t);            // Z3 = 2*Z1*H  (= (Z1+H)^2 - Z1Z1 - HH)
+    el_sqr(t, rr);
+    el_sub(t, t, j);
+    el_sub(t, t, v);
+    el_sub(acc.x, t, v);         // X3 = r^2 - J - 2V
+    el_mul(j, acc.y, j);         // Y1*J
+    el_sub(v, v, acc.x);
+    el_mul(v, rr, v);            // r*(V - X3)
+    el_sub(v, v, j);
+    el_sub(acc.y, v, j);         // Y3
+}
+
+// r = a + b, both Jacobian.
+template <class E>
+AMDMSM_DEV void jac_add(Jac<E>& r, const Jac<E>& a, const Jac<E>& b) {
+    if (jac_is_inf(a)) {
+        r = b;
+        return;
+    }
+    if (jac_is_inf(b)) {
+        r = a;
+        return;
+    }
+    E z1z1, z2z2, u1, u2, s1, s2, h, i, j, rr, v, t;
+    el_sqr(z1z1, a.z);
+    el_sqr(z2z2, b.z);
+    el_mul(u1, a.x, z2z2);
+    el_mul(u2, b.x, z1z1);
+    el_mul(s1, b.z, z2z2);
+    el_mul(s1, a.y, s1);
+    el_mul(s2, a.z, z1z1);
+    el_mul(s2, b.y, s2);
+    if (el_eq(u1, u2) && el_eq(s1, s2)) {
+        jac_dbl(r, a);
+        return;
+    }
+    el_sub(h, u2, u1);
+    el_dbl(t, h);
+    el_sqr(i, t);                // I = (2H)^2
+    el_mul(j, h, i);             // J
+    el_sub(rr, s2, s1);
+    el_dbl(rr, rr);              // r
+    el_mul(v, u1, i);            // V
+    el_mul(t, a.z, b.z);
+    el_mul(t, t, h);
+    el_dbl(r.z, t);              // Z3 = 2*Z1*Z2*H
+    el_sqr(t, rr);
+    el_sub(t, t, j);
+    el_sub(t, t, v);
+    el_sub(r.x, t, v);           // X3
+    el_mul(j, s1, j);            // S1*J
+    el_sub(v, v, r.x);
+    el_mul(v, rr, v);
+    el_sub(v, v, j);
+    el_sub(r.y, v, j);           // Y3
+}
+
+template <class E>
+AMDMSM_DEV void jac_to_aff(Aff<E>& r, const Jac<E>& p) {
+    if (jac_is_inf(p)) {
+        el_zero(r.x);
+        el_zero(r.y);
+        return;
+    }
+    E zi, z2;
+    el_inv(zi, p.z);
+    el_sqr(z2, zi);
+    el_mul(r.x, p.x, z2);
+    el_mul(z2, z2, zi);
+    el_mul(r.y, p.y, z2);
+}
+
+// k * P by double-and-add (curve_utils.tcc:14-32 shape), k < 2^64
+template <class E>
+AMDMSM_DEV void jac_mul_u64(Jac<E>& r, const Jac<E>& p, unsigned long long k) {
+    Jac<E> acc;
+    jac_set_inf(acc);
+    if (k != 0) {
+        for (int i = 63 - __clzll((long long)k); i >= 0; --i) {
+            jac_dbl(acc, acc);
+            if ((k >> i) & 1ull) jac_add(acc, acc, p);
+        }
+    }
+    r = acc;
+}
+
+}  // namespace amdmsm

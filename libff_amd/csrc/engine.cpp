@@ -1,0 +1,563 @@
+// Host side of the amdmsm C ABI (include/amdmsm.h): context, workspace, the MSM
+// pipeline schedule and the host-buffer entry points.  All arithmetic happens in
+// the kernels of msm_group.hip; there is no CPU arithmetic path in this library.
+#include "../../include/amdmsm.h"
+#include "group_vtable.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+using namespace amdmsm;
+
+struct amdmsm_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    void *ws = nullptr;
+    size_t ws_bytes = 0;
+    bool timing = false;
+    hipEvent_t ev[AMDMSM_MAX_PHASES + 1] = {};
+    bool ev_valid = false;
+    hipStream_t ev_stream = nullptr;
+    std::string err;
+    std::mutex mu;
+};
+
+namespace {
+
+// The six group translation units are linked weakly so a development build may carry a
+// subset (AMDMSM_GROUPS=... python -m libff_amd.build); absent groups report UNSUPPORTED.
+using vt_getter = const group_vtable *(*)();
+const group_vtable *find_vt(int curve, int group) {
+    static const vt_getter getters[] = {
+        vt_alt_bn128_g1, vt_alt_bn128_g2, vt_bls12_377_g1, vt_bls12_377_g2, vt_bw6_761_g1, vt_bw6_761_g2,
+    };
+    for (vt_getter g : getters) {
+        if (!g) continue;
+        const group_vtable *v = g();
+        if (v->curve == curve && v->group == group) return v;
+    }
+    return nullptr;
+}
+
+int fail(amdmsm_ctx *ctx, int code, const std::string &msg) {
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                   \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            return fail(ctx, AMDMSM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+        }                                                                                    \
+    } while (0)
+
+// libff::log2 (ceil), utils.cpp:32-44
+size_t libff_log2(size_t n) {
+    size_t r = ((n & (n - 1)) == 0 ? 0 : 1);
+    while (n > 1) {
+        n >>= 1;
+        r++;
+    }
+    return r;
+}
+
+struct plan_t {
+    int c = 0, W = 0;
+    uint32_t B = 0, L = 0;
+    size_t off_counts = 0, off_lists = 0, off_buckets = 0, off_lvl0 = 0, off_lvl1 = 0, total = 0;
+    size_t list_stride = 0;
+};
+
+size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Window size: minimise  W(c) * (n * madd + 2^(c-1) * 2 * add)  in field multiplications.
+int choose_c(const group_vtable *vt, size_t n) {
+    if (n == 0) return 2;
+    double best = 1e300;
+    int best_c = 2;
+    for (int c = 2; c <= 22; ++c) {
+        const double W = (double)((vt->fr_bits + 2 + c - 1) / c);
+        const double B = (double)((size_t)1 << (c - 1));
+        const double cost = W * ((double)n * 11.0 + B * (2.0 * 17.0 + 2.0));
+        if (cost < best) {
+            best = cost;
+            best_c = c;
+        }
+    }
+    return best_c;
+}
+
+int make_plan(const group_vtable *vt, size_t n, int c_req, int L_req, plan_t &p) {
+    if (c_req < 0 || c_req > 24 || c_req == 1) return AMDMSM_ERR_BAD_ARG;
+    p.c = c_req ? c_req : choose_c(vt, n);
+    // field_get_signed_digit needs room for bits + 2 (multiexp.tcc:584-586)
+    p.W = (vt->fr_bits + 2 + p.c - 1) / p.c;
+    p.B = (uint32_t)1 << (p.c - 1);
+    uint32_t L = L_req > 0 ? (uint32_t)L_req : 32u;
+    while (L > p.B) L >>= 1;
+    if (L == 0 || (L & (L - 1))) return AMDMSM_ERR_BAD_ARG;
+    p.L = L;
+    const size_t xyz_bytes = (size_t)3 * vt->el_words * 4;
+    p.list_stride = align_up(n ? n : 1, 64);
+    size_t off = 0;
+    p.off_counts = off;
+    off = align_up(off + (size_t)p.W * p.B * 4, 256);
+    p.off_lists = off;
+    off = align_up(off + (size_t)p.W * p.list_stride * 4, 256);
+    p.off_buckets = off;
+    off = align_up(off + (size_t)p.W * p.B * xyz_bytes, 256);
+    const size_t M = p.B / p.L;
+    p.off_lvl0 = off;
+    off = align_up(off + (size_t)p.W * M * xyz_bytes, 256);
+    p.off_lvl1 = off;
+    off = align_up(off + (size_t)p.W * ((M + p.L - 1) / p.L) * xyz_bytes, 256);
+    p.total = off;
+    return AMDMSM_OK;
+}
+
+int ensure_ws(amdmsm_ctx *ctx, size_t bytes) {
+    if (ctx->ws_bytes >= bytes) return AMDMSM_OK;
+    if (ctx->ws) {
+        HIP_TRY(ctx, hipDeviceSynchronize());
+        HIP_TRY(ctx, hipFree(ctx->ws));
+        ctx->ws = nullptr;
+        ctx->ws_bytes = 0;
+    }
+    const size_t want = bytes + bytes / 8;
+    HIP_TRY(ctx, hipMalloc(&ctx->ws, want));
+    ctx->ws_bytes = want;
+    return AMDMSM_OK;
+}
+
+struct dev_guard {
+    int prev = -1;
+    explicit dev_guard(int dev) {
+        (void)hipGetDevice(&prev);
+        if (prev != dev) (void)hipSetDevice(dev);
+        else prev = -1;
+    }
+    ~dev_guard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+void record(amdmsm_ctx *ctx, int idx, hipStream_t st) {
+    if (ctx->timing) (void)hipEventRecord(ctx->ev[idx], st);
+}
+
+// The whole single-GPU MSM on device-resident inputs.
+int msm_device_impl(amdmsm_ctx *ctx, const group_vtable *vt, const uint32_t *d_bases, const uint32_t *d_scalars,
+                    size_t n, uint32_t *d_out, const amdmsm_opts *opts) {
+    hipStream_t st = (opts && opts->stream) ? (hipStream_t)opts->stream : ctx->stream;
+    const int form = opts ? opts->out_form : AMDMSM_OUT_LIBFF;
+    const int mont = (opts && opts->scalars_plain) ? 0 : 1;
+    if (n >= ((size_t)1 << 31)) return fail(ctx, AMDMSM_ERR_TOO_LARGE, "n must be < 2^31 per call");
+    if (n == 0) {
+        // empty sum = zero; sum_points over 0 points writes G::zero() in the requested form
+        vt->sum_points(st, d_out, 0, form, d_out);
+        HIP_TRY(ctx, hipGetLastError());
+        return AMDMSM_OK;
+    }
+    plan_t p;
+    int rc = make_plan(vt, n, opts ? opts->window_bits : 0, opts ? opts->segment_len : 0, p);
+    if (rc) return fail(ctx, rc, "bad window_bits / segment_len");
+    rc = ensure_ws(ctx, p.total);
+    if (rc) return rc;
+    char *ws = (char *)ctx->ws;
+    uint32_t *counts = (uint32_t *)(ws + p.off_counts);
+    uint32_t *lists = (uint32_t *)(ws + p.off_lists);
+    uint32_t *buckets = (uint32_t *)(ws + p.off_buckets);
+    uint32_t *lvl0 = (uint32_t *)(ws + p.off_lvl0);
+    uint32_t *lvl1 = (uint32_t *)(ws + p.off_lvl1);
+
+    ctx->ev_stream = st;
+    record(ctx, 0, st);
+    HIP_TRY(ctx, hipMemsetAsync(counts, 0, (size_t)p.W * p.B * 4, st));
+    vt->count(st, d_scalars, n, mont, p.c, p.W, counts);
+    record(ctx, 1, st);
+    vt->scatter(st, d_scalars, n, mont, p.c, p.W, counts, lists, p.list_stride);
+    record(ctx, 2, st);
+    vt->accumulate(st, counts, lists, p.list_stride, d_bases, buckets, p.W, p.B);
+    record(ctx, 3, st);
+    vt->reduce_segments(st, buckets, p.W, p.B, p.L, lvl0);
+    uint32_t M = p.B / p.L;
+    uint32_t *src = lvl0, *dst = lvl1;
+    while (M > 1) {
+        vt->sum_level(st, src, p.W, M, p.L, dst);
+        M = (M + p.L - 1) / p.L;
+        std::swap(src, dst);
+    }
+    record(ctx, 4, st);
+    vt->horner(st, src, p.W, p.c, form, d_out);
+    record(ctx, 5, st);
+    ctx->ev_valid = ctx->timing;
+    HIP_TRY(ctx, hipGetLastError());
+    return AMDMSM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int amdmsm_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *amdmsm_strerror(int code) {
+    switch (code) {
+    case AMDMSM_OK: return "ok";
+    case AMDMSM_ERR_NO_DEVICE: return "no gfx950 device available (this library has no CPU path)";
+    case AMDMSM_ERR_BAD_ARG: return "bad argument";
+    case AMDMSM_ERR_UNSUPPORTED: return "unsupported curve/group";
+    case AMDMSM_ERR_HIP: return "HIP runtime error";
+    case AMDMSM_ERR_TOO_LARGE: return "input too large for one call";
+    default: return "unknown error";
+    }
+}
+
+const char *amdmsm_last_error(const amdmsm_ctx *ctx) { return ctx ? ctx->err.c_str() : ""; }
+
+int amdmsm_ctx_create(int device, amdmsm_ctx **out) {
+    if (!out) return AMDMSM_ERR_BAD_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return AMDMSM_ERR_NO_DEVICE;
+    if (device < 0 || device >= ndev) return AMDMSM_ERR_BAD_ARG;
+    amdmsm_ctx *ctx = new amdmsm_ctx();
+    ctx->device = device;
+    dev_guard g(device);
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return AMDMSM_ERR_HIP;
+    }
+    for (auto &e : ctx->ev) {
+        if (hipEventCreate(&e) != hipSuccess) {
+            delete ctx;
+            return AMDMSM_ERR_HIP;
+        }
+    }
+    *out = ctx;
+    return AMDMSM_OK;
+}
+
+void amdmsm_ctx_destroy(amdmsm_ctx *ctx) {
+    if (!ctx) return;
+    {
+        dev_guard g(ctx->device);
+        (void)hipDeviceSynchronize();
+        if (ctx->ws) (void)hipFree(ctx->ws);
+        for (auto &e : ctx->ev) {
+            if (e) (void)hipEventDestroy(e);
+        }
+        if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    }
+    delete ctx;
+}
+
+int amdmsm_sizes(int curve, int group, size_t out[4]) {
+    const group_vtable *vt = find_vt(curve, group);
+    if (!vt || !out) return AMDMSM_ERR_UNSUPPORTED;
+    out[0] = (size_t)vt->fr_words * 4;
+    out[1] = (size_t)vt->el_words * 3 * 4;
+    out[2] = (size_t)vt->el_words * 2 * 4;
+    out[3] = (size_t)vt->fr_bits;
+    return AMDMSM_OK;
+}
+
+int amdmsm_plan(int curve, int group, size_t n, int window_bits, int *c, int *num_windows, uint32_t *num_buckets,
+                size_t *workspace_bytes) {
+    const group_vtable *vt = find_vt(curve, group);
+    if (!vt) return AMDMSM_ERR_UNSUPPORTED;
+    plan_t p;
+    const int rc = make_plan(vt, n, window_bits, 0, p);
+    if (rc) return rc;
+    if (c) *c = p.c;
+    if (num_windows) *num_windows = p.W;
+    if (num_buckets) *num_buckets = p.B;
+    if (workspace_bytes) *workspace_bytes = p.total;
+    return AMDMSM_OK;
+}
+
+size_t amdmsm_pippenger_optimal_c(size_t num_elements) {
+    // multiexp.tcc:35-40 (size_t wrap-around arithmetic kept as is)
+    const size_t l = libff_log2(num_elements);
+    return l - (l / 3 - 2);
+}
+
+size_t amdmsm_bdlo12_signed_optimal_c(size_t num_elements) {
+    return amdmsm_pippenger_optimal_c(num_elements) + 1;   // multiexp.tcc:637-641
+}
+
+int amdmsm_set_timing(amdmsm_ctx *ctx, int enable) {
+    if (!ctx) return AMDMSM_ERR_BAD_ARG;
+    ctx->timing = enable != 0;
+    ctx->ev_valid = false;
+    return AMDMSM_OK;
+}
+
+int amdmsm_get_timings(amdmsm_ctx *ctx, float ms[AMDMSM_MAX_PHASES]) {
+    if (!ctx || !ms) return AMDMSM_ERR_BAD_ARG;
+    for (int i = 0; i < AMDMSM_MAX_PHASES; ++i) ms[i] = 0.f;
+    if (!ctx->ev_valid) return fail(ctx, AMDMSM_ERR_BAD_ARG, "no timed amdmsm_msm_device call recorded");
+    dev_guard g(ctx->device);
+    HIP_TRY(ctx, hipEventSynchronize(ctx->ev[5]));
+    for (int i = 0; i < 5; ++i) HIP_TRY(ctx, hipEventElapsedTime(&ms[i], ctx->ev[i], ctx->ev[i + 1]));
+    HIP_TRY(ctx, hipEventElapsedTime(&ms[AMDMSM_PH_TOTAL], ctx->ev[0], ctx->ev[5]));
+    return AMDMSM_OK;
+}
+
+#define GET_VT(ctx, curve, group)                                         \
+    if (!ctx) return AMDMSM_ERR_BAD_ARG;                                  \
+    const group_vtable *vt = find_vt(curve, group);                       \
+    if (!vt) return fail(ctx, AMDMSM_ERR_UNSUPPORTED, "unknown curve/group"); \
+    std::lock_guard<std::mutex> lock_(ctx->mu);                           \
+    dev_guard guard_(ctx->device)
+
+int amdmsm_msm_device(amdmsm_ctx *ctx, int curve, int group, const void *d_bases_affine, const void *d_scalars,
+                      size_t n, void *d_out_xyz, const amdmsm_opts *opts) {
+    GET_VT(ctx, curve, group);
+    if (!d_out_xyz || (n && (!d_bases_affine || !d_scalars))) return fail(ctx, AMDMSM_ERR_BAD_ARG, "null pointer");
+    return msm_device_impl(ctx, vt, (const uint32_t *)d_bases_affine, (const uint32_t *)d_scalars, n,
+                           (uint32_t *)d_out_xyz, opts);
+}
+
+int amdmsm_import_bases_device(amdmsm_ctx *ctx, int curve, int group, const void *d_src_xyz, size_t stride_bytes,
+                               int base_form, size_t n, void *d_dst_affine, void *stream) {
+    GET_VT(ctx, curve, group);
+    if (stride_bytes % 16 || stride_bytes < (size_t)vt->el_words * 12) return fail(ctx, AMDMSM_ERR_BAD_ARG, "stride");
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    vt->import_bases(st, (const uint32_t *)d_src_xyz, stride_bytes / 4, base_form == AMDMSM_FORM_SPECIAL, n,
+                     (uint32_t *)d_dst_affine);
+    HIP_TRY(ctx, hipGetLastError());
+    return AMDMSM_OK;
+}
+
+int amdmsm_export_affine_device(amdmsm_ctx *ctx, int curve, int group, const void *d_src_affine, size_t n,
+                                void *d_dst_xyz, void *stream) {
+    GET_VT(ctx, curve, group);
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    vt->export_affine(st, (const uint32_t *)d_src_affine, n, (uint32_t *)d_dst_xyz);
+    HIP_TRY(ctx, hipGetLastError());
+    return AMDMSM_OK;
+}
+
+int amdmsm_sum_points_device(amdmsm_ctx *ctx, int curve, int group, const void *d_points_jacobian, int k,
+                             int out_form, void *d_out_xyz, void *stream) {
+    GET_VT(ctx, curve, group);
+    if (k < 0 || !d_out_xyz) return fail(ctx, AMDMSM_ERR_BAD_ARG, "k");
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    vt->sum_points(st, (const uint32_t *)d_points_jacobian, k, out_form, (uint32_t *)d_out_xyz);
+    HIP_TRY(ctx, hipGetLastError());
+    return AMDMSM_OK;
+}
+
+int amdmsm_gen_bases_seq_device(amdmsm_ctx *ctx, int curve, int group, uint64_t first, size_t n, void *d_dst_affine,
+                                void *stream) {
+    GET_VT(ctx, curve, group);
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    vt->gen_bases_seq(st, first, n, (uint32_t *)d_dst_affine);
+    HIP_TRY(ctx, hipGetLastError());
+    return AMDMSM_OK;
+}
+
+int amdmsm_field_op_device(amdmsm_ctx *ctx, int curve, int group, int op, const void *d_a, const void *d_b,
+                           void *d_out, size_t n) {
+    GET_VT(ctx, curve, group);
+    vt->field_op(ctx->stream, op, (const uint32_t *)d_a, (const uint32_t *)d_b, (uint32_t *)d_out, n);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return AMDMSM_OK;
+}
+
+int amdmsm_group_op_device(amdmsm_ctx *ctx, int curve, int group, int op, const void *d_a, const void *d_b,
+                           void *d_out, size_t n, int out_form) {
+    GET_VT(ctx, curve, group);
+    vt->group_op(ctx->stream, op, (const uint32_t *)d_a, (const uint32_t *)d_b, (uint32_t *)d_out, n, out_form);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return AMDMSM_OK;
+}
+
+int amdmsm_digits_device(amdmsm_ctx *ctx, int curve, int group, const void *d_scalars, size_t n, int scalars_plain,
+                         int c, int num_windows, int32_t *d_out) {
+    GET_VT(ctx, curve, group);
+    if (c < 2 || c > 24 || num_windows < 1) return fail(ctx, AMDMSM_ERR_BAD_ARG, "c / num_windows");
+    vt->digits(ctx->stream, (const uint32_t *)d_scalars, n, scalars_plain ? 0 : 1, c, num_windows, d_out);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return AMDMSM_OK;
+}
+
+int amdmsm_mul_bench_device(amdmsm_ctx *ctx, int curve, int group, void *d_inout, size_t nthreads, int iters,
+                            int inline_variant, float *ms) {
+    GET_VT(ctx, curve, group);
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[AMDMSM_MAX_PHASES - 1], ctx->stream));
+    vt->mul_bench(ctx->stream, (uint32_t *)d_inout, nthreads, iters, inline_variant);
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[AMDMSM_MAX_PHASES], ctx->stream));
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventSynchronize(ctx->ev[AMDMSM_MAX_PHASES]));
+    if (ms) HIP_TRY(ctx, hipEventElapsedTime(ms, ctx->ev[AMDMSM_MAX_PHASES - 1], ctx->ev[AMDMSM_MAX_PHASES]));
+    return AMDMSM_OK;
+}
+
+int amdmsm_madd_bench_device(amdmsm_ctx *ctx, int curve, int group, const void *d_points_affine, void *d_out_xyz,
+                             size_t nthreads, int iters, int inline_variant, float *ms) {
+    GET_VT(ctx, curve, group);
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[AMDMSM_MAX_PHASES - 1], ctx->stream));
+    vt->madd_bench(ctx->stream, (const uint32_t *)d_points_affine, (uint32_t *)d_out_xyz, nthreads, iters,
+                   inline_variant);
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[AMDMSM_MAX_PHASES], ctx->stream));
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventSynchronize(ctx->ev[AMDMSM_MAX_PHASES]));
+    if (ms) HIP_TRY(ctx, hipEventElapsedTime(ms, ctx->ev[AMDMSM_MAX_PHASES - 1], ctx->ev[AMDMSM_MAX_PHASES]));
+    return AMDMSM_OK;
+}
+
+int amdmsm_malloc(amdmsm_ctx *ctx, size_t bytes, void **d_ptr) {
+    if (!ctx || !d_ptr) return AMDMSM_ERR_BAD_ARG;
+    dev_guard g(ctx->device);
+    HIP_TRY(ctx, hipMalloc(d_ptr, bytes ? bytes : 16));
+    return AMDMSM_OK;
+}
+
+int amdmsm_free(amdmsm_ctx *ctx, void *d_ptr) {
+    if (!ctx) return AMDMSM_ERR_BAD_ARG;
+    dev_guard g(ctx->device);
+    HIP_TRY(ctx, hipFree(d_ptr));
+    return AMDMSM_OK;
+}
+
+int amdmsm_memcpy_h2d(amdmsm_ctx *ctx, void *d_dst, const void *h_src, size_t bytes) {
+    if (!ctx) return AMDMSM_ERR_BAD_ARG;
+    dev_guard g(ctx->device);
+    HIP_TRY(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return AMDMSM_OK;
+}
+
+int amdmsm_memcpy_d2h(amdmsm_ctx *ctx, void *h_dst, const void *d_src, size_t bytes) {
+    if (!ctx) return AMDMSM_ERR_BAD_ARG;
+    dev_guard g(ctx->device);
+    HIP_TRY(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return AMDMSM_OK;
+}
+
+int amdmsm_synchronize(amdmsm_ctx *ctx) {
+    if (!ctx) return AMDMSM_ERR_BAD_ARG;
+    dev_guard g(ctx->device);
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    return AMDMSM_OK;
+}
+
+// ------------------------------------------------------------ host entries
+int amdmsm_multi_exp(amdmsm_ctx *ctx, int curve, int group, const void *bases_xyz, size_t base_stride_bytes,
+                     int base_form, const void *scalars, size_t n, void *out_xyz, const amdmsm_opts *opts) {
+    GET_VT(ctx, curve, group);
+    if (!out_xyz || (n && (!bases_xyz || !scalars))) return fail(ctx, AMDMSM_ERR_BAD_ARG, "null pointer");
+    const size_t xyz_bytes = (size_t)vt->el_words * 12, aff_bytes = (size_t)vt->el_words * 8;
+    const size_t fr_bytes = (size_t)vt->fr_words * 4;
+    if (base_stride_bytes == 0) base_stride_bytes = xyz_bytes;
+    if (base_stride_bytes % 16 || base_stride_bytes < xyz_bytes) return fail(ctx, AMDMSM_ERR_BAD_ARG, "base stride");
+    hipStream_t st = ctx->stream;
+    void *d_src = nullptr, *d_aff = nullptr, *d_sc = nullptr, *d_out = nullptr;
+    int rc = AMDMSM_OK;
+    auto cleanup = [&]() {
+        if (d_src) (void)hipFree(d_src);
+        if (d_aff) (void)hipFree(d_aff);
+        if (d_sc) (void)hipFree(d_sc);
+        if (d_out) (void)hipFree(d_out);
+    };
+#define TRY_CLEAN(expr)                                                                              \
+    do {                                                                                             \
+        hipError_t e_ = (expr);                                                                      \
+        if (e_ != hipSuccess) {                                                                      \
+            cleanup();                                                                               \
+            return fail(ctx, AMDMSM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));     \
+        }                                                                                            \
+    } while (0)
+    TRY_CLEAN(hipMalloc(&d_out, xyz_bytes));
+    if (n) {
+        TRY_CLEAN(hipMalloc(&d_src, n * base_stride_bytes));
+        TRY_CLEAN(hipMalloc(&d_aff, n * aff_bytes));
+        TRY_CLEAN(hipMalloc(&d_sc, n * fr_bytes));
+        TRY_CLEAN(hipMemcpyAsync(d_src, bases_xyz, n * base_stride_bytes, hipMemcpyHostToDevice, st));
+        TRY_CLEAN(hipMemcpyAsync(d_sc, scalars, n * fr_bytes, hipMemcpyHostToDevice, st));
+        vt->import_bases(st, (const uint32_t *)d_src, base_stride_bytes / 4, base_form == AMDMSM_FORM_SPECIAL, n,
+                         (uint32_t *)d_aff);
+    }
+    amdmsm_opts o = {};
+    if (opts) o = *opts;
+    else o.out_form = AMDMSM_OUT_LIBFF;
+    o.stream = st;
+    rc = msm_device_impl(ctx, vt, (const uint32_t *)d_aff, (const uint32_t *)d_sc, n, (uint32_t *)d_out, &o);
+    if (rc == AMDMSM_OK) {
+        TRY_CLEAN(hipMemcpyAsync(out_xyz, d_out, xyz_bytes, hipMemcpyDeviceToHost, st));
+        TRY_CLEAN(hipStreamSynchronize(st));
+    }
+    cleanup();
+    return rc;
+#undef TRY_CLEAN
+}
+
+int amdmsm_multi_exp_filter_one_zero(amdmsm_ctx *ctx, int curve, int group, const void *bases_xyz,
+                                     size_t base_stride_bytes, int base_form, const void *scalars, size_t n,
+                                     void *out_xyz, const amdmsm_opts *opts, size_t stats[3]) {
+    // multiexp.tcc:690-757 separates scalars equal to 0 and 1 before the Pippenger
+    // pass.  On the device a zero scalar recodes to all-zero digits (no work) and a
+    // one lands in bucket 1 of window 0, so the same kernels compute the same sum;
+    // only the three statistics the reference prints need the classification.
+    if (stats) {
+        const group_vtable *vt = find_vt(curve, group);
+        if (!vt) return AMDMSM_ERR_UNSUPPORTED;
+        const size_t fr_bytes = (size_t)vt->fr_words * 4;
+        std::vector<unsigned char> zero(fr_bytes, 0), one(fr_bytes, 0);
+        if (opts && opts->scalars_plain) one[0] = 1;
+        else memcpy(one.data(), vt->fr_one_mont, fr_bytes);   // FieldT::one(), multiexp.tcc:723
+        stats[0] = stats[1] = stats[2] = 0;
+        for (size_t i = 0; i < n; ++i) {
+            const unsigned char *s = (const unsigned char *)scalars + i * fr_bytes;
+            if (memcmp(s, zero.data(), fr_bytes) == 0) ++stats[0];
+            else if (memcmp(s, one.data(), fr_bytes) == 0) ++stats[1];
+            else ++stats[2];
+        }
+    }
+    return amdmsm_multi_exp(ctx, curve, group, bases_xyz, base_stride_bytes, base_form, scalars, n, out_xyz, opts);
+}
+
+int amdmsm_batch_to_special(amdmsm_ctx *ctx, int curve, int group, void *elems_xyz, size_t stride_bytes, size_t n) {
+    GET_VT(ctx, curve, group);
+    const size_t xyz_bytes = (size_t)vt->el_words * 12, aff_bytes = (size_t)vt->el_words * 8;
+    if (stride_bytes == 0) stride_bytes = xyz_bytes;
+    if (stride_bytes != xyz_bytes) return fail(ctx, AMDMSM_ERR_BAD_ARG, "batch_to_special needs packed records");
+    if (!n) return AMDMSM_OK;
+    hipStream_t st = ctx->stream;
+    void *d_src = nullptr, *d_aff = nullptr;
+    HIP_TRY(ctx, hipMalloc(&d_src, n * xyz_bytes));
+    if (hipMalloc(&d_aff, n * aff_bytes) != hipSuccess) {
+        (void)hipFree(d_src);
+        return fail(ctx, AMDMSM_ERR_HIP, "hipMalloc");
+    }
+    hipError_t e = hipMemcpyAsync(d_src, elems_xyz, n * xyz_bytes, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        vt->import_bases(st, (const uint32_t *)d_src, xyz_bytes / 4, 0, n, (uint32_t *)d_aff);
+        vt->export_affine(st, (const uint32_t *)d_aff, n, (uint32_t *)d_src);
+        e = hipMemcpyAsync(elems_xyz, d_src, n * xyz_bytes, hipMemcpyDeviceToHost, st);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(d_src);
+    (void)hipFree(d_aff);
+    if (e != hipSuccess) return fail(ctx, AMDMSM_ERR_HIP, hipGetErrorString(e));
+    return AMDMSM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,294 @@
+// Prime-field arithmetic for gfx950 (CDNA4), 32-bit limbs held in VGPRs.
+//
+// Device-side counterpart of libff's Fp_model<n, modulus> (fp.hpp:38-160):
+//   mul      <- mul_reduce          fp.tcc:50-228   (Montgomery, R = 2^(32N) = 2^(64n))
+//   sqr      <- squared             fp.tcc:632-677
+//   add/sub  <- operator+= / -=     fp.tcc:350-547
+//   neg      <- operator-           fp.tcc:616-630
+//   from_mont<- as_bigint           fp.tcc:270-281
+// Representation is libff's: fully reduced Montgomery residue in [0, p), limb 0
+// least significant; a libff bigint<n> (64-bit limbs) reinterpreted as 2n x u32
+// on a little-endian host is exactly this layout, so no conversion is needed.
+//
+// The hot op is the N x N word CIOS Montgomery product.  It is written around
+// v_mad_u64_u32 (32x32+64 -> 64, one issue) with fully unrolled loops so every
+// limb lives in a named VGPR and the modulus limbs become SGPR/literal operands.
+// All three moduli leave the top bit of the top limb clear, so the running
+// value never exceeds 2p < 2^(32N) and no (N+1)-th accumulator word is needed.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace amdmsm {
+
+#define AMDMSM_DEV __device__ __forceinline__
+
+// INL selects how the Montgomery product is emitted for this element type:
+//   true   fully inlined at every use (hot loops of narrow fields)
+//   false  one out-of-line copy per translation unit, operands passed by value in
+//          VGPRs (keeps the instruction footprint of wide-field / cold kernels inside
+//          the 64 KB instruction cache and the build time sane)
+template <class P, bool INL = true>
+struct Fp {
+    static constexpr int N = P::N;
+    using params = P;
+    uint32_t v[N];
+};
+
+template <class P, bool I>
+AMDMSM_DEV void fp_set_zero(Fp<P, I>& r) {
+#pragma unroll
+    for (int i = 0; i < P::N; ++i) r.v[i] = 0;
+}
+
+template <class P, bool I>
+AMDMSM_DEV void fp_set_one(Fp<P, I>& r) {   // Montgomery 1 = R mod p
+#pragma unroll
+    for (int i = 0; i < P::N; ++i) r.v[i] = P::R[i];
+}
+
+template <class P, bool I>
+AMDMSM_DEV bool fp_is_zero(const Fp<P, I>& a) {
+    uint32_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < P::N; ++i) acc |= a.v[i];
+    return acc == 0;
+}
+
+template <class P, bool I>
+AMDMSM_DEV bool fp_eq(const Fp<P, I>& a, const Fp<P, I>& b) {
+    uint32_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < P::N; ++i) acc |= (a.v[i] ^ b.v[i]);
+    return acc == 0;
+}
+
+// r = a - p if a >= p (a < 2p), branch-free select.
+template <class P>
+AMDMSM_DEV void fp_reduce_once(uint32_t (&t)[P::N]) {
+    uint32_t d[P::N];
+    uint32_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < P::N; ++i) {
+        const uint64_t s = (uint64_t)t[i] - P::P[i] - borrow;
+        d[i] = (uint32_t)s;
+        borrow = (uint32_t)(s >> 63);
+    }
+#pragma unroll
+    for (int i = 0; i < P::N; ++i) t[i] = borrow ? t[i] : d[i];
+}
+
+template <class P, bool I>
+AMDMSM_DEV void fp_add(Fp<P, I>& r, const Fp<P, I>& a, const Fp<P, I>& b) {
+    uint32_t t[P::N];
+    uint32_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < P::N; ++i) {
+        const uint64_t s = (uint64_t)a.v[i] + b.v[i] + carry;
+        t[i] = (uint32_t)s;
+        carry = (uint32_t)(s >> 32);
+    }
+    // p < 2^(32N-1): a + b < 2p < 2^(32N), so the carry out is always 0
+    fp_reduce_once<P>(t);
+#pragma unroll
+    for (int i = 0; i < P::N; ++i) r.v[i] = t[i];
+}
+
+template <class P, bool I>
+AMDMSM_DEV void fp_sub(Fp<P, I>& r, const Fp<P, I>& a, const Fp<P, I>& b) {
+    uint32_t t[P::N];
+    uint32_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < P::N; ++i) {
+        const uint64_t s = (uint64_t)a.v[i] - b.v[i] - borrow;
+        t[i] = (uint32_t)s;
+        borrow = (uint32_t)(s >> 63);
+    }
+    // add p back when the subtraction borrowed
+    const uint32_t mask = 0u - borrow;
+    uint32_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < P::N; ++i) {
+        const uint64_t s = (uint64_t)t[i] + (P::P[i] & mask) + carry;
+        r.v[i] = (uint32_t)s;
+        carry = (uint32_t)(s >> 32);
+    }
+}
+
+template <class P, bool I>
+AMDMSM_DEV void fp_dbl(Fp<P, I>& r, const Fp<P, I>& a) {
+    uint32_t t[P::N];
+    uint32_t hi = 0;
+#pragma unroll
+    for (int i = 0; i < P::N; ++i) {
+        t[i] = (a.v[i] << 1) | hi;
+        hi = a.v[i] >> 31;
+    }
+    fp_reduce_once<P>(t);
+#pragma unroll
+    for (int i = 0; i < P::N; ++i) r.v[i] = t[i];
+}
+
+template <class P, bool I>
+AMDMSM_DEV void fp_neg(Fp<P, I>& r, const Fp<P, I>& a) {
+    const uint32_t mask = fp_is_zero(a) ? 0u : 0xffffffffu;   // -0 = 0 (fp.tcc:623-628)
+    uint32_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < P::N; ++i) {
+        const uint64_t s = (uint64_t)P::P[i] - a.v[i] - borrow;
+        r.v[i] = (uint32_t)s & mask;
+        borrow = (uint32_t)(s >> 63);
+    }
+}
+
+// conditional negate: r = neg ? -a : a
+template <class P, bool I>
+AMDMSM_DEV void fp_cneg(Fp<P, I>& r, const Fp<P, I>& a, bool neg) {
+    Fp<P, I> n;
+    fp_neg(n, a);
+#pragma unroll
+    for (int i = 0; i < P::N; ++i) r.v[i] = neg ? n.v[i] : a.v[i];
+}
+
+// Montgomery product, CIOS, operand scanning (fp.tcc:50-228 computes the same
+// value with 64-bit limbs; R = 2^(32N) is identical).
+template <class P>
+AMDMSM_DEV void fp_mul_core(uint32_t (&r)[P::N], const uint32_t (&a)[P::N], const uint32_t (&b)[P::N]) {
+    constexpr int N = P::N;
+    uint32_t t[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) t[i] = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const uint32_t bi = b[i];
+        uint64_t c = (uint64_t)a[0] * bi + t[0];
+        const uint32_t m = (uint32_t)c * P::INV;
+        uint64_t c2 = (uint64_t)m * P::P[0] + (uint32_t)c;
+#pragma unroll
+        for (int j = 1; j < N; ++j) {
+            c = (uint64_t)a[j] * bi + t[j] + (c >> 32);
+            c2 = (uint64_t)m * P::P[j] + (uint32_t)c + (c2 >> 32);
+            t[j - 1] = (uint32_t)c2;
+        }
+        t[N - 1] = (uint32_t)(c >> 32) + (uint32_t)(c2 >> 32);
+    }
+    fp_reduce_once<P>(t);
+#pragma unroll
+    for (int i = 0; i < N; ++i) r[i] = t[i];
+}
+
+template <class P>
+struct fp_words {
+    uint32_t v[P::N];
+};
+
+template <class P>
+__device__ __noinline__ fp_words<P> fp_mul_call(fp_words<P> a, fp_words<P> b) {
+    fp_words<P> r;
+    fp_mul_core<P>(r.v, a.v, b.v);
+    return r;
+}
+
+template <class P, bool I>
+AMDMSM_DEV void fp_mul(Fp<P, I>& r, const Fp<P, I>& a, const Fp<P, I>& b) {
+    if constexpr (I) {
+        fp_mul_core<P>(r.v, a.v, b.v);
+    } else {
+        fp_words<P> x, y;
+#pragma unroll
+        for (int i = 0; i < P::N; ++i) {
+            x.v[i] = a.v[i];
+            y.v[i] = b.v[i];
+        }
+        const fp_words<P> z = fp_mul_call<P>(x, y);
+#pragma unroll
+        for (int i = 0; i < P::N; ++i) r.v[i] = z.v[i];
+    }
+}
+
+template <class P, bool I>
+AMDMSM_DEV void fp_sqr(Fp<P, I>& r, const Fp<P, I>& a) {
+    fp_mul(r, a, a);
+}
+
+// Montgomery reduction of a single element: a * R^-1 mod p  (as_bigint, fp.tcc:270-281)
+template <class P, bool I>
+AMDMSM_DEV void fp_from_mont(Fp<P, I>& r, const Fp<P, I>& a) {
+    constexpr int N = P::N;
+    uint32_t t[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) t[i] = a.v[i];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const uint32_t m = t[0] * P::INV;
+        uint64_t c2 = (uint64_t)m * P::P[0] + t[0];
+#pragma unroll
+        for (int j = 1; j < N; ++j) {
+            c2 = (uint64_t)m * P::P[j] + t[j] + (c2 >> 32);
+            t[j - 1] = (uint32_t)c2;
+        }
+        t[N - 1] = (uint32_t)(c2 >> 32);
+    }
+    fp_reduce_once<P>(t);
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.v[i] = t[i];
+}
+
+template <class P, bool I>
+AMDMSM_DEV void fp_to_mont(Fp<P, I>& r, const Fp<P, I>& a) {   // Fp_model(bigint) ctor, fp.tcc:230-235
+    Fp<P, I> r2;
+#pragma unroll
+    for (int i = 0; i < P::N; ++i) r2.v[i] = P::R2[i];
+    fp_mul(r, a, r2);
+}
+
+// a^(p-2) (Fermat).  libff uses mpn_gcdext (fp.tcc:679-727); same field element.
+// Only used off the hot path (affine output, batch normalisation: one per thread).
+template <class P, bool I>
+AMDMSM_DEV void fp_inv(Fp<P, I>& r, const Fp<P, I>& a) {
+    constexpr int N = P::N;
+    Fp<P, I> acc;
+    fp_set_one(acc);
+    // exponent = p - 2, scanned MSB first; p is odd and p[0] >= 3 for our moduli
+    for (int i = N * 32 - 1; i >= 0; --i) {
+        uint32_t w = P::P[0];
+        // select limb i/32 of (p - 2) without a runtime-indexed private array
+        const int li = i >> 5;
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            uint32_t pk = P::P[k];
+            if (k == 0) pk -= 2u;   // no borrow: p[0] >= 2
+            w = (li == k) ? pk : w;
+        }
+        fp_sqr(acc, acc);
+        if ((w >> (i & 31)) & 1u) fp_mul(acc, acc, a);
+    }
+    r = acc;
+}
+
+template <class P, bool I>
+AMDMSM_DEV void fp_load(Fp<P, I>& r, const uint32_t* __restrict__ p) {
+    constexpr int N = P::N;
+    static_assert(N % 4 == 0, "limb count must be a multiple of 4 for 16-byte loads");
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+#pragma unroll
+    for (int i = 0; i < N / 4; ++i) {
+        const uint4 w = q[i];
+        r.v[4 * i + 0] = w.x;
+        r.v[4 * i + 1] = w.y;
+        r.v[4 * i + 2] = w.z;
+        r.v[4 * i + 3] = w.w;
+    }
+}
+
+template <class P, bool I>
+AMDMSM_DEV void fp_store(uint32_t* __restrict__ p, const Fp<P, I>& a) {
+    constexpr int N = P::N;
+    uint4* q = reinterpret_cast<uint4*>(p);
+#pragma unroll
+    for (int i = 0; i < N / 4; ++i) {
+        q[i] = make_uint4(a.v[4 * i + 0], a.v[4 * i + 1], a.v[4 * i + 2], a.v[4 * i + 3]);
+    }
+}
+
+}  // namespace amdmsm

@@ -1,0 +1,140 @@
+// Quadratic extension Fq2 = Fq[u]/(u^2 - NR) for the G2 groups (libff Fp2_model,
+// fp2.tcc:78-151).  NR is a small negative integer for both supported towers
+// (-1 alt_bn128, alt_bn128_init.cpp:138-140; -5 bls12_377, bls12_377_init.cpp:174-176),
+// so "multiply by the non-residue" is a few additions instead of the full Fq
+// multiplication the reference performs (same field element).
+//
+// The el_* overload set gives the curve code one spelling for both coordinate
+// fields (Fq for G1 / bw6_761, Fq2 for the twists).
+#pragma once
+#include "fp.cuh"
+
+namespace amdmsm {
+
+template <class P, int NR, bool I = true>
+struct Fp2 {
+    using params = P;
+    static constexpr int N = 2 * P::N;   // 32-bit words per element
+    Fp<P, I> c0, c1;
+};
+
+// x * |NR| by additions, then negate (NR < 0)
+template <class P, int NR, bool I>
+AMDMSM_DEV void fp_mul_nr(Fp<P, I>& r, const Fp<P, I>& x) {
+    static_assert(NR == -1 || NR == -5, "unsupported non-residue");
+    if (NR == -1) {
+        fp_neg(r, x);
+    } else {
+        Fp<P, I> t;
+        fp_dbl(t, x);
+        fp_dbl(t, t);
+        fp_add(t, t, x);
+        fp_neg(r, t);
+    }
+}
+
+// ---- Fq overloads ---------------------------------------------------------
+template <class P, bool I> AMDMSM_DEV void el_zero(Fp<P, I>& r) { fp_set_zero(r); }
+template <class P, bool I> AMDMSM_DEV void el_one(Fp<P, I>& r) { fp_set_one(r); }
+template <class P, bool I> AMDMSM_DEV bool el_is_zero(const Fp<P, I>& a) { return fp_is_zero(a); }
+template <class P, bool I> AMDMSM_DEV bool el_eq(const Fp<P, I>& a, const Fp<P, I>& b) { return fp_eq(a, b); }
+template <class P, bool I> AMDMSM_DEV void el_add(Fp<P, I>& r, const Fp<P, I>& a, const Fp<P, I>& b) { fp_add(r, a, b); }
+template <class P, bool I> AMDMSM_DEV void el_sub(Fp<P, I>& r, const Fp<P, I>& a, const Fp<P, I>& b) { fp_sub(r, a, b); }
+template <class P, bool I> AMDMSM_DEV void el_dbl(Fp<P, I>& r, const Fp<P, I>& a) { fp_dbl(r, a); }
+template <class P, bool I> AMDMSM_DEV void el_neg(Fp<P, I>& r, const Fp<P, I>& a) { fp_neg(r, a); }
+template <class P, bool I> AMDMSM_DEV void el_cneg(Fp<P, I>& r, const Fp<P, I>& a, bool n) { fp_cneg(r, a, n); }
+template <class P, bool I> AMDMSM_DEV void el_mul(Fp<P, I>& r, const Fp<P, I>& a, const Fp<P, I>& b) { fp_mul(r, a, b); }
+template <class P, bool I> AMDMSM_DEV void el_sqr(Fp<P, I>& r, const Fp<P, I>& a) { fp_sqr(r, a); }
+template <class P, bool I> AMDMSM_DEV void el_inv(Fp<P, I>& r, const Fp<P, I>& a) { fp_inv(r, a); }
+template <class P, bool I> AMDMSM_DEV void el_load(Fp<P, I>& r, const uint32_t* p) { fp_load(r, p); }
+template <class P, bool I> AMDMSM_DEV void el_store(uint32_t* p, const Fp<P, I>& a) { fp_store(p, a); }
+template <class P, bool I> AMDMSM_DEV void el_set_words(Fp<P, I>& r, const uint32_t (&w)[P::N]) {
+#pragma unroll
+    for (int i = 0; i < P::N; ++i) r.v[i] = w[i];
+}
+
+// ---- Fq2 overloads --------------------------------------------------------
+template <class P, int NR, bool I> AMDMSM_DEV void el_zero(Fp2<P, NR, I>& r) { fp_set_zero(r.c0); fp_set_zero(r.c1); }
+template <class P, int NR, bool I> AMDMSM_DEV void el_one(Fp2<P, NR, I>& r) { fp_set_one(r.c0); fp_set_zero(r.c1); }
+template <class P, int NR, bool I> AMDMSM_DEV bool el_is_zero(const Fp2<P, NR, I>& a) {
+    return fp_is_zero(a.c0) && fp_is_zero(a.c1);
+}
+template <class P, int NR, bool I> AMDMSM_DEV bool el_eq(const Fp2<P, NR, I>& a, const Fp2<P, NR, I>& b) {
+    return fp_eq(a.c0, b.c0) && fp_eq(a.c1, b.c1);
+}
+template <class P, int NR, bool I> AMDMSM_DEV void el_add(Fp2<P, NR, I>& r, const Fp2<P, NR, I>& a, const Fp2<P, NR, I>& b) {
+    fp_add(r.c0, a.c0, b.c0);   // fp2.tcc:78-85
+    fp_add(r.c1, a.c1, b.c1);
+}
+template <class P, int NR, bool I> AMDMSM_DEV void el_sub(Fp2<P, NR, I>& r, const Fp2<P, NR, I>& a, const Fp2<P, NR, I>& b) {
+    fp_sub(r.c0, a.c0, b.c0);   // fp2.tcc:87-94
+    fp_sub(r.c1, a.c1, b.c1);
+}
+template <class P, int NR, bool I> AMDMSM_DEV void el_dbl(Fp2<P, NR, I>& r, const Fp2<P, NR, I>& a) {
+    fp_dbl(r.c0, a.c0);
+    fp_dbl(r.c1, a.c1);
+}
+template <class P, int NR, bool I> AMDMSM_DEV void el_neg(Fp2<P, NR, I>& r, const Fp2<P, NR, I>& a) {
+    fp_neg(r.c0, a.c0);         // fp2.tcc:116-120
+    fp_neg(r.c1, a.c1);
+}
+template <class P, int NR, bool I> AMDMSM_DEV void el_cneg(Fp2<P, NR, I>& r, const Fp2<P, NR, I>& a, bool n) {
+    fp_cneg(r.c0, a.c0, n);
+    fp_cneg(r.c1, a.c1, n);
+}
+// Karatsuba, fp2.tcc:101-114: (aA + NR*bB, (a+b)(A+B) - aA - bB)
+template <class P, int NR, bool I> AMDMSM_DEV void el_mul(Fp2<P, NR, I>& r, const Fp2<P, NR, I>& x, const Fp2<P, NR, I>& y) {
+    Fp<P, I> aA, bB, s1, s2, t;
+    fp_mul(aA, x.c0, y.c0);
+    fp_mul(bB, x.c1, y.c1);
+    fp_add(s1, x.c0, x.c1);
+    fp_add(s2, y.c0, y.c1);
+    fp_mul(s1, s1, s2);
+    fp_sub(s1, s1, aA);
+    fp_sub(s1, s1, bB);
+    fp_mul_nr<P, NR, I>(t, bB);
+    fp_add(r.c0, aA, t);
+    r.c1 = s1;
+}
+// complex squaring, fp2.tcc:141-151: ((a+b)(a+NR*b) - ab - NR*ab, 2ab)
+template <class P, int NR, bool I> AMDMSM_DEV void el_sqr(Fp2<P, NR, I>& r, const Fp2<P, NR, I>& x) {
+    Fp<P, I> ab, s1, s2, t;
+    fp_mul(ab, x.c0, x.c1);
+    fp_add(s1, x.c0, x.c1);
+    fp_mul_nr<P, NR, I>(t, x.c1);
+    fp_add(s2, x.c0, t);
+    fp_mul(s1, s1, s2);
+    fp_sub(s1, s1, ab);
+    fp_mul_nr<P, NR, I>(t, ab);
+    fp_sub(r.c0, s1, t);
+    fp_dbl(r.c1, ab);
+}
+// fp2 inverse: (a - b u) / (a^2 - NR b^2)
+template <class P, int NR, bool I> AMDMSM_DEV void el_inv(Fp2<P, NR, I>& r, const Fp2<P, NR, I>& x) {
+    Fp<P, I> t0, t1, t2;
+    fp_sqr(t0, x.c0);
+    fp_sqr(t1, x.c1);
+    fp_mul_nr<P, NR, I>(t2, t1);
+    fp_sub(t0, t0, t2);
+    fp_inv(t1, t0);
+    fp_mul(r.c0, x.c0, t1);
+    fp_mul(t2, x.c1, t1);
+    fp_neg(r.c1, t2);
+}
+template <class P, int NR, bool I> AMDMSM_DEV void el_load(Fp2<P, NR, I>& r, const uint32_t* p) {
+    fp_load(r.c0, p);
+    fp_load(r.c1, p + P::N);
+}
+template <class P, int NR, bool I> AMDMSM_DEV void el_set_words(Fp2<P, NR, I>& r, const uint32_t (&w)[2 * P::N]) {
+#pragma unroll
+    for (int i = 0; i < P::N; ++i) {
+        r.c0.v[i] = w[i];
+        r.c1.v[i] = w[P::N + i];
+    }
+}
+template <class P, int NR, bool I> AMDMSM_DEV void el_store(uint32_t* p, const Fp2<P, NR, I>& a) {
+    fp_store(p, a.c0);
+    fp_store(p + P::N, a.c1);
+}
+
+}  // namespace amdmsm

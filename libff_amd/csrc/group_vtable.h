@@ -1,0 +1,72 @@
+// Host-side table of kernel launchers for one (curve, group) pair.  One
+// translation unit (msm_group.hip compiled with -DAMDMSM_GROUP=<traits>) fills one
+// table; the engine (engine.cpp) is written against this table only.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace amdmsm {
+
+// output coordinate conventions for the final kernels
+enum out_form : int {
+    OUT_JACOBIAN = 0,   // engine-internal Jacobian (X, Y, Z); used for partial results
+    OUT_LIBFF = 1,      // libff's in-memory coordinate system for the group (projective for bw6_761)
+    OUT_AFFINE = 2,     // libff "special" form: (x, y, 1) or zero = (0, 1, 0)
+};
+
+struct group_vtable {
+    int curve, group;
+    int fr_words;      // 32-bit words per scalar
+    int el_words;      // 32-bit words per coordinate (Fq or Fq2)
+    int fr_bits;       // bit length of the scalar-field modulus
+    int projective;    // libff stores this group in homogeneous projective coordinates
+    const uint32_t* fr_one_mont;   // Fr::one() in Montgomery form (R mod r), fr_words words
+
+    // libff (X, Y, Z) records -> compact affine (x, y); (0, 0) = infinity.
+    // form_special != 0 promises Z == 1 or zero (multi_exp_base_form_special).
+    void (*import_bases)(hipStream_t, const uint32_t* src, size_t stride_words, int form_special,
+                         size_t n, uint32_t* dst_affine);
+    // histogram of signed radix-2^c digits: counts[w * B + (|d| - 1)]++
+    void (*count)(hipStream_t, const uint32_t* scalars, size_t n, int mont, int c, int W, uint32_t* counts);
+    // cursor[] holds exclusive bucket starts on entry, bucket ends on exit
+    void (*scatter)(hipStream_t, const uint32_t* scalars, size_t n, int mont, int c, int W, uint32_t* cursor,
+                    uint32_t* lists, size_t list_stride);
+    void (*accumulate)(hipStream_t, const uint32_t* ends, const uint32_t* lists, size_t list_stride,
+                       const uint32_t* bases_affine, uint32_t* buckets, int W, uint32_t B);
+    // out[w][s] = sum_j (s*L + j + 1) * bucket[w][s*L + j]
+    void (*reduce_segments)(hipStream_t, const uint32_t* buckets, int W, uint32_t B, uint32_t L, uint32_t* out);
+    // out[w][s] = sum_{j < L} in[w][s*L + j]
+    void (*sum_level)(hipStream_t, const uint32_t* in, int W, uint32_t M, uint32_t L, uint32_t* out);
+    // Horner over window sums (high to low, c doublings between), write one point
+    void (*horner)(hipStream_t, const uint32_t* window_sums, int W, int c, int form, uint32_t* out);
+    // sum of k engine-Jacobian points
+    void (*sum_points)(hipStream_t, const uint32_t* pts, int k, int form, uint32_t* out);
+    // synthetic bases: dst[i] = (first + i + 1) * G::one(), compact affine
+    void (*gen_bases_seq)(hipStream_t, unsigned long long first, size_t n, uint32_t* dst_affine);
+    // compact affine -> libff special-form records (x, y, 1) / (0, 1, 0)
+    void (*export_affine)(hipStream_t, const uint32_t* src_affine, size_t n, uint32_t* dst_xyz);
+
+    // ---- test hooks (parity of the primitives against the oracle) ----------
+    // coordinate-field op over arrays: 0 mul 1 sqr 2 add 3 sub 4 neg 5 inverse
+    void (*field_op)(hipStream_t, int op, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t n);
+    // group op over arrays of libff-layout records (Jacobian groups: same formulas as
+    // libff; bw6_761: converted through affine): 0 add 1 mixed_add 2 dbl; out in `form`
+    void (*group_op)(hipStream_t, int op, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t n, int form);
+    // signed digits of each scalar: out[i * W + w]
+    void (*digits)(hipStream_t, const uint32_t* scalars, size_t n, int mont, int c, int W, int32_t* out);
+    // throughput probes: 2*iters dependent Fq products / iters mixed additions per lane
+    // (inline_variant selects the fully inlined product where the TU was built with it)
+    void (*mul_bench)(hipStream_t, uint32_t* inout, size_t nthreads, int iters, int inline_variant);
+    void (*madd_bench)(hipStream_t, const uint32_t* pts_affine, uint32_t* out_xyz, size_t nthreads, int iters,
+                       int inline_variant);
+};
+
+const group_vtable* vt_alt_bn128_g1() __attribute__((weak));
+const group_vtable* vt_alt_bn128_g2() __attribute__((weak));
+const group_vtable* vt_bls12_377_g1() __attribute__((weak));
+const group_vtable* vt_bls12_377_g2() __attribute__((weak));
+const group_vtable* vt_bw6_761_g1() __attribute__((weak));
+const group_vtable* vt_bw6_761_g2() __attribute__((weak));
+
+}  // namespace amdmsm

@@ -1,0 +1,563 @@
+// MSM kernels for ONE (curve, group) pair on gfx950.  Compiled once per group with
+//   -DAMDMSM_GROUP=<traits struct from curve_params.h> -DAMDMSM_VT=<vtable getter>
+// so the six groups build in parallel and every modulus limb is a compile-time
+// constant in the instruction stream.
+//
+// Pipeline (the device-side restatement of multi_exp_inner<BDLO12_signed>,
+// multiexp.tcc:563-632, re-shaped for a throughput machine):
+//   k_count      signed radix-2^c recoding of every scalar (field_get_signed_digit,
+//                field_utils.tcc:167-203) -> per-(window, bucket) histogram
+//   k_scan       exclusive scan of the histogram, one workgroup per window
+//   k_scatter    second recoding pass -> per-window point lists grouped by bucket
+//   k_accumulate one lane per (window, bucket): mixed additions of its run of points
+//                (multi_exp_add_element_to_bucket_with_signed_digit, multiexp.tcc:45-81)
+//   k_reduce_segments / k_sum_level
+//                sum_b (b+1) * B_b (multiexp_accumulate_buckets, multiexp.tcc:90-125)
+//                as L-bucket running sums + a small scalar multiple per segment,
+//                then an L-ary tree of plain sums
+//   k_horner     high-to-low window combination with c doublings (multiexp.tcc:612-629)
+//
+// All windows are processed at once: the libff loop "for round ... signed_digits_round"
+// becomes the W dimension of every grid.
+#include "curve_params.h"
+#include "ec.cuh"
+#include "group_vtable.h"
+
+#ifndef AMDMSM_GROUP
+#error "compile with -DAMDMSM_GROUP=<group traits> -DAMDMSM_VT=<vtable getter name>"
+#endif
+
+namespace amdmsm {
+namespace {
+
+using GP = AMDMSM_GROUP;
+using FQ = typename GP::fq;
+using FR = typename GP::fr;
+
+// Montgomery products are emitted inline only where AMDMSM_HOT_INLINE asks for it (the
+// bucket-accumulation loop of narrow fields); everywhere else they are calls to one
+// out-of-line copy per translation unit (fp.cuh, Fp<P, INL>).
+#ifndef AMDMSM_HOT_INLINE
+#define AMDMSM_HOT_INLINE 0
+#endif
+#ifndef AMDMSM_BENCH_BOTH
+#define AMDMSM_BENCH_BOTH 0
+#endif
+template <int DEG, bool I> struct coord_sel;
+template <bool I> struct coord_sel<1, I> { using type = Fp<FQ, I>; };
+template <bool I> struct coord_sel<2, I> { using type = Fp2<FQ, GP::NR_SMALL == 0 ? -1 : GP::NR_SMALL, I>; };
+using E = typename coord_sel<GP::DEG, false>::type;                     // cold kernels
+using EH = typename coord_sel<GP::DEG, (AMDMSM_HOT_INLINE != 0)>::type;  // k_accumulate
+using EI = typename coord_sel<GP::DEG, true>::type;                      // probes only
+
+constexpr int EW = FQ::N * GP::DEG;   // words per coordinate
+constexpr int AFFW = 2 * EW;          // words per compact affine point
+constexpr int XYZW = 3 * EW;          // words per (X, Y, Z) record
+constexpr int FRW = FR::N;            // words per scalar
+constexpr int TPB = 256;
+
+AMDMSM_DEV size_t gtid() { return (size_t)blockIdx.x * blockDim.x + threadIdx.x; }
+
+template <class T> AMDMSM_DEV void load_aff(Aff<T>& p, const uint32_t* q) {
+    el_load(p.x, q);
+    el_load(p.y, q + EW);
+}
+template <class T> AMDMSM_DEV void store_aff(uint32_t* q, const Aff<T>& p) {
+    el_store(q, p.x);
+    el_store(q + EW, p.y);
+}
+template <class T> AMDMSM_DEV void load_jac(Jac<T>& p, const uint32_t* q) {
+    el_load(p.x, q);
+    el_load(p.y, q + EW);
+    el_load(p.z, q + 2 * EW);
+}
+template <class T> AMDMSM_DEV void store_jac(uint32_t* q, const Jac<T>& p) {
+    el_store(q, p.x);
+    el_store(q + EW, p.y);
+    el_store(q + 2 * EW, p.z);
+}
+
+// libff in-memory record -> engine Jacobian
+AMDMSM_DEV void load_libff(Jac<E>& p, const uint32_t* q) {
+    load_jac(p, q);
+    if (GP::LIBFF_PROJECTIVE) {
+        // (X : Y : Z) homogeneous, x = X/Z, y = Y/Z  ->  Jacobian (X*Z, Y*Z^2, Z)
+        if (el_is_zero(p.z)) {
+            jac_set_inf(p);
+        } else {
+            E zz;
+            el_sqr(zz, p.z);
+            el_mul(p.x, p.x, p.z);
+            el_mul(p.y, p.y, zz);
+        }
+    }
+}
+
+// engine Jacobian -> requested output convention
+AMDMSM_DEV void store_out(uint32_t* q, const Jac<E>& p, int form) {
+    Jac<E> o;
+    if (form == OUT_JACOBIAN) {
+        o = p;
+    } else if (jac_is_inf(p)) {
+        jac_set_inf(o);   // libff zero = (0, 1, 0) in every coordinate system used here
+    } else if (form == OUT_AFFINE) {
+        Aff<E> a;
+        jac_to_aff(a, p);
+        o.x = a.x;
+        o.y = a.y;
+        el_one(o.z);
+    } else if (GP::LIBFF_PROJECTIVE) {
+        // Jacobian (X, Y, Z): x = X/Z^2, y = Y/Z^3  ->  homogeneous (X*Z : Y : Z^3)
+        E zz;
+        el_sqr(zz, p.z);
+        el_mul(o.x, p.x, p.z);
+        o.y = p.y;
+        el_mul(o.z, zz, p.z);
+    } else {
+        o = p;
+    }
+    store_jac(q, o);
+}
+
+// ---------------------------------------------------------------- recoding
+// Signed radix-2^c digits, least-significant window first, exactly
+// field_get_signed_digits (field_utils.tcc:205-239): digit = raw + carry;
+// overflow (digit == 2^c) -> 0 with carry; bit c-1 set -> digit - 2^c with carry.
+// The scalar is streamed through a 64-bit bit buffer so no private array is
+// indexed at run time (which would send it to scratch).
+template <class F>
+AMDMSM_DEV void for_each_signed_digit(const uint32_t (&s)[FRW], int c, int W, F&& emit) {
+    const uint32_t mask = (1u << c) - 1u;
+    uint64_t buf = 0;
+    int nbits = 0;
+    int w = 0;
+    uint32_t carry = 0;
+    auto step = [&](uint32_t raw) {
+        const uint32_t digit = raw + carry;
+        const uint32_t overflow = (digit >> c) & 1u;
+        const uint32_t cbit = (digit >> (c - 1)) & 1u;
+        const int32_t d = overflow ? 0 : (int32_t)digit - (int32_t)(cbit << c);
+        carry = overflow | cbit;
+        emit(w, d);
+        ++w;
+    };
+#pragma unroll
+    for (int j = 0; j < FRW; ++j) {
+        buf |= (uint64_t)s[j] << nbits;
+        nbits += 32;
+        while (nbits >= c && w < W) {
+            step((uint32_t)buf & mask);
+            buf >>= c;
+            nbits -= c;
+        }
+    }
+    while (w < W) {
+        step((uint32_t)buf & mask);
+        buf >>= c;
+    }
+}
+
+AMDMSM_DEV void load_scalar(uint32_t (&s)[FRW], const uint32_t* scalars, size_t i, int mont) {
+    Fp<FR> x;
+    fp_load(x, scalars + i * FRW);
+    if (mont) fp_from_mont(x, x);   // Fp_model::as_bigint, multiexp.tcc:579-582
+#pragma unroll
+    for (int j = 0; j < FRW; ++j) s[j] = x.v[j];
+}
+
+__global__ void __launch_bounds__(TPB) k_count(const uint32_t* __restrict__ scalars, size_t n, int mont, int c, int W,
+                                               uint32_t* __restrict__ counts) {
+    const size_t i = gtid();
+    if (i >= n) return;
+    uint32_t s[FRW];
+    load_scalar(s, scalars, i, mont);
+    const size_t B = (size_t)1 << (c - 1);
+    for_each_signed_digit(s, c, W, [&](int w, int32_t d) {
+        if (d != 0) {
+            const uint32_t idx = (uint32_t)(d < 0 ? -d : d) - 1u;
+            atomicAdd(&counts[(size_t)w * B + idx], 1u);
+        }
+    });
+}
+
+__global__ void __launch_bounds__(TPB) k_scatter(const uint32_t* __restrict__ scalars, size_t n, int mont, int c, int W,
+                                                 uint32_t* __restrict__ cursor, uint32_t* __restrict__ lists,
+                                                 size_t list_stride) {
+    const size_t i = gtid();
+    if (i >= n) return;
+    uint32_t s[FRW];
+    load_scalar(s, scalars, i, mont);
+    const size_t B = (size_t)1 << (c - 1);
+    for_each_signed_digit(s, c, W, [&](int w, int32_t d) {
+        if (d != 0) {
+            const uint32_t neg = d < 0 ? 1u : 0u;
+            const uint32_t idx = (uint32_t)(neg ? -d : d) - 1u;
+            const uint32_t pos = atomicAdd(&cursor[(size_t)w * B + idx], 1u);
+            lists[(size_t)w * list_stride + pos] = (uint32_t)i | (neg << 31);
+        }
+    });
+}
+
+__global__ void __launch_bounds__(TPB) k_digits(const uint32_t* __restrict__ scalars, size_t n, int mont, int c, int W,
+                                                int32_t* __restrict__ out) {
+    const size_t i = gtid();
+    if (i >= n) return;
+    uint32_t s[FRW];
+    load_scalar(s, scalars, i, mont);
+    for_each_signed_digit(s, c, W, [&](int w, int32_t d) { out[i * (size_t)W + w] = d; });
+}
+
+// Exclusive scan of one window's histogram per workgroup (grid.x = W).
+constexpr int SCAN_TPB = 1024;
+constexpr int SCAN_ITEMS = 4;
+__global__ void __launch_bounds__(SCAN_TPB) k_scan(uint32_t* __restrict__ counts, uint32_t B) {
+    __shared__ uint32_t wave_sums[SCAN_TPB / 64];
+    __shared__ uint32_t running;
+    uint32_t* p = counts + (size_t)blockIdx.x * B;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) running = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < B; base += SCAN_TPB * SCAN_ITEMS) {
+        const uint32_t i0 = base + threadIdx.x * SCAN_ITEMS;
+        uint32_t v[SCAN_ITEMS];
+        uint32_t tsum = 0;
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; ++k) {
+            v[k] = (i0 + k < B) ? p[i0 + k] : 0u;
+            tsum += v[k];
+        }
+        // inclusive scan of per-thread sums inside the wave
+        uint32_t inc = tsum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += o;
+        }
+        if (lane == 63) wave_sums[wave] = inc;
+        __syncthreads();
+        uint32_t wave_off = 0, total = 0;
+#pragma unroll
+        for (int k = 0; k < SCAN_TPB / 64; ++k) {
+            const uint32_t ws = wave_sums[k];
+            if (k < wave) wave_off += ws;
+            total += ws;
+        }
+        uint32_t excl = running + wave_off + inc - tsum;
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; ++k) {
+            if (i0 + k < B) p[i0 + k] = excl;
+            excl += v[k];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) running += total;
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------ accumulation
+__global__ void __launch_bounds__(TPB) k_accumulate(const uint32_t* __restrict__ ends, const uint32_t* __restrict__ lists,
+                                                    size_t list_stride, const uint32_t* __restrict__ bases,
+                                                    uint32_t* __restrict__ buckets, int W, uint32_t B) {
+    const size_t t = gtid();
+    const size_t w = t / B;
+    const uint32_t b = (uint32_t)(t % B);
+    if (w >= (size_t)W) return;
+    const uint32_t* e = ends + w * B;
+    const uint32_t start = b ? e[b - 1] : 0u;
+    const uint32_t end = e[b];
+    const uint32_t* lst = lists + w * list_stride;
+    Jac<EH> acc;
+    jac_set_inf(acc);
+    for (uint32_t k = start; k < end; ++k) {
+        const uint32_t ent = lst[k];
+        const uint32_t idx = ent & 0x7fffffffu;
+        Aff<EH> p;
+        load_aff(p, bases + (size_t)idx * AFFW);
+        el_cneg(p.y, p.y, (ent >> 31) != 0);   // -(x, y) = (x, -y); (0,0) stays infinity
+        jac_madd(acc, p);
+    }
+    store_jac(buckets + t * XYZW, acc);
+}
+
+// --------------------------------------------------------------- reduction
+__global__ void __launch_bounds__(TPB) k_reduce_segments(const uint32_t* __restrict__ buckets, int W, uint32_t B,
+                                                         uint32_t L, uint32_t* __restrict__ out) {
+    const size_t t = gtid();
+    const uint32_t M = B / L;
+    const size_t w = t / M;
+    const uint32_t s = (uint32_t)(t % M);
+    if (w >= (size_t)W) return;
+    const uint32_t* seg = buckets + (w * B + (size_t)s * L) * XYZW;
+    Jac<E> acc, sum, bk;
+    jac_set_inf(acc);
+    jac_set_inf(sum);
+    for (uint32_t j = L; j-- > 0;) {
+        load_jac(bk, seg + (size_t)j * XYZW);
+        jac_add(acc, acc, bk);    // acc = sum_{k >= j} B_k
+        jac_add(sum, sum, acc);   // sum = sum_k (k - j + 1) B_k
+    }
+    // segment's buckets carry weights s*L + j + 1: add (s*L) * acc
+    jac_mul_u64(bk, acc, (unsigned long long)s * L);
+    jac_add(sum, sum, bk);
+    store_jac(out + t * XYZW, sum);
+}
+
+__global__ void __launch_bounds__(TPB) k_sum_level(const uint32_t* __restrict__ in, int W, uint32_t M, uint32_t L,
+                                                   uint32_t* __restrict__ out) {
+    const size_t t = gtid();
+    const uint32_t Mo = (M + L - 1) / L;
+    const size_t w = t / Mo;
+    const uint32_t s = (uint32_t)(t % Mo);
+    if (w >= (size_t)W) return;
+    Jac<E> acc, x;
+    jac_set_inf(acc);
+    const uint32_t lo = s * L, hi = (lo + L < M) ? lo + L : M;
+    for (uint32_t j = lo; j < hi; ++j) {
+        load_jac(x, in + (w * M + j) * XYZW);
+        jac_add(acc, acc, x);
+    }
+    store_jac(out + t * XYZW, acc);
+}
+
+__global__ void k_horner(const uint32_t* __restrict__ window_sums, int W, int c, int form, uint32_t* __restrict__ out) {
+    if (gtid() != 0) return;
+    Jac<E> res, x;
+    load_jac(res, window_sums + (size_t)(W - 1) * XYZW);
+    for (int w = W - 2; w >= 0; --w) {
+        for (int i = 0; i < c; ++i) jac_dbl(res, res);
+        load_jac(x, window_sums + (size_t)w * XYZW);
+        jac_add(res, res, x);
+    }
+    store_out(out, res, form);
+}
+
+__global__ void k_sum_points(const uint32_t* __restrict__ pts, int k, int form, uint32_t* __restrict__ out) {
+    if (gtid() != 0) return;
+    Jac<E> res, x;
+    jac_set_inf(res);
+    for (int i = 0; i < k; ++i) {
+        load_jac(x, pts + (size_t)i * XYZW);
+        jac_add(res, res, x);
+    }
+    store_out(out, res, form);
+}
+
+// ------------------------------------------------------------ base import
+__global__ void __launch_bounds__(TPB) k_import_bases(const uint32_t* __restrict__ src, size_t stride_words,
+                                                      int form_special, size_t n, uint32_t* __restrict__ dst) {
+    const size_t i = gtid();
+    if (i >= n) return;
+    const uint32_t* q = src + i * stride_words;
+    Aff<E> a;
+    if (form_special) {
+        // Z == 1 or the element is zero (is_special, alt_bn128_g1.cpp:86-89)
+        E z;
+        el_load(a.x, q);
+        el_load(a.y, q + EW);
+        el_load(z, q + 2 * EW);
+        if (el_is_zero(z)) {
+            el_zero(a.x);
+            el_zero(a.y);
+        }
+    } else {
+        Jac<E> p;
+        load_libff(p, q);
+        jac_to_aff(a, p);
+    }
+    store_aff(dst + i * AFFW, a);
+}
+
+__global__ void __launch_bounds__(TPB) k_export_affine(const uint32_t* __restrict__ src, size_t n,
+                                                       uint32_t* __restrict__ dst) {
+    const size_t i = gtid();
+    if (i >= n) return;
+    Aff<E> a;
+    load_aff(a, src + i * AFFW);
+    Jac<E> p;
+    jac_from_aff(p, a);
+    store_jac(dst + i * XYZW, p);
+}
+
+AMDMSM_DEV void load_generator(Jac<E>& g) {
+    el_set_words(g.x, GP::GEN_X);
+    el_set_words(g.y, GP::GEN_Y);
+    el_one(g.z);
+}
+
+__global__ void __launch_bounds__(TPB) k_gen_bases_seq(unsigned long long first, size_t n, uint32_t* __restrict__ dst) {
+    const size_t i = gtid();
+    if (i >= n) return;
+    Jac<E> g, r;
+    load_generator(g);
+    jac_mul_u64(r, g, first + i + 1ull);
+    Aff<E> a;
+    jac_to_aff(a, r);
+    store_aff(dst + i * AFFW, a);
+}
+
+// -------------------------------------------------------------- test hooks
+__global__ void __launch_bounds__(TPB) k_field_op(int op, const uint32_t* __restrict__ a, const uint32_t* __restrict__ b,
+                                                  uint32_t* __restrict__ out, size_t n) {
+    const size_t i = gtid();
+    if (i >= n) return;
+    E x, y, r;
+    el_load(x, a + i * EW);
+    if (b) el_load(y, b + i * EW); else el_zero(y);
+    switch (op) {
+    case 0: el_mul(r, x, y); break;
+    case 1: el_sqr(r, x); break;
+    case 2: el_add(r, x, y); break;
+    case 3: el_sub(r, x, y); break;
+    case 4: el_neg(r, x); break;
+    case 5: el_inv(r, x); break;
+    default: el_zero(r); break;
+    }
+    el_store(out + i * EW, r);
+}
+
+__global__ void __launch_bounds__(TPB) k_group_op(int op, const uint32_t* __restrict__ a, const uint32_t* __restrict__ b,
+                                                  uint32_t* __restrict__ out, size_t n, int form) {
+    const size_t i = gtid();
+    if (i >= n) return;
+    Jac<E> p, q, r;
+    load_libff(p, a + i * XYZW);
+    if (op == 0) {
+        load_libff(q, b + i * XYZW);
+        jac_add(r, p, q);
+    } else if (op == 1) {
+        // second operand is in special form: Z == 1 or zero
+        load_jac(q, b + i * XYZW);
+        Aff<E> qa;
+        if (el_is_zero(q.z)) {
+            el_zero(qa.x);
+            el_zero(qa.y);
+        } else {
+            qa.x = q.x;
+            qa.y = q.y;
+        }
+        r = p;
+        jac_madd(r, qa);
+    } else {
+        jac_dbl(r, p);
+    }
+    store_out(out + i * XYZW, r, form);
+}
+
+// Throughput probes: a dependent chain of Montgomery products / mixed additions per lane,
+// operands in registers, no memory traffic inside the loop.
+template <bool I>
+__global__ void __launch_bounds__(TPB) k_mul_bench(uint32_t* __restrict__ inout, size_t nthreads, int iters) {
+    const size_t i = gtid();
+    if (i >= nthreads) return;
+    Fp<FQ, I> x, y;
+    fp_load(x, inout + i * FQ::N);
+    y = x;
+    for (int k = 0; k < iters; ++k) {
+        fp_mul(x, x, y);
+        fp_mul(y, y, x);
+    }
+    fp_add(x, x, y);
+    fp_store(inout + i * FQ::N, x);
+}
+
+template <class T>
+__global__ void __launch_bounds__(TPB) k_madd_bench(const uint32_t* __restrict__ pts, uint32_t* __restrict__ out,
+                                                    size_t nthreads, int iters) {
+    const size_t i = gtid();
+    if (i >= nthreads) return;
+    Aff<T> p;
+    load_aff(p, pts + i * AFFW);
+    Jac<T> acc;
+    jac_from_aff(acc, p);
+    jac_dbl(acc, acc);
+    for (int k = 0; k < iters; ++k) jac_madd(acc, p);
+    store_jac(out + i * XYZW, acc);
+}
+
+// ---------------------------------------------------------------- launchers
+inline unsigned blocks_for(size_t n, int tpb = TPB) { return (unsigned)((n + tpb - 1) / tpb); }
+
+void l_import_bases(hipStream_t st, const uint32_t* src, size_t stride_words, int form_special, size_t n, uint32_t* dst) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_import_bases, dim3(blocks_for(n)), dim3(TPB), 0, st, src, stride_words, form_special, n, dst);
+}
+void l_count(hipStream_t st, const uint32_t* scalars, size_t n, int mont, int c, int W, uint32_t* counts) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_count, dim3(blocks_for(n)), dim3(TPB), 0, st, scalars, n, mont, c, W, counts);
+    hipLaunchKernelGGL(k_scan, dim3(W), dim3(SCAN_TPB), 0, st, counts, (uint32_t)1 << (c - 1));
+}
+void l_scatter(hipStream_t st, const uint32_t* scalars, size_t n, int mont, int c, int W, uint32_t* cursor,
+               uint32_t* lists, size_t list_stride) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_scatter, dim3(blocks_for(n)), dim3(TPB), 0, st, scalars, n, mont, c, W, cursor, lists, list_stride);
+}
+void l_accumulate(hipStream_t st, const uint32_t* ends, const uint32_t* lists, size_t list_stride, const uint32_t* bases,
+                  uint32_t* buckets, int W, uint32_t B) {
+    hipLaunchKernelGGL(k_accumulate, dim3(blocks_for((size_t)W * B)), dim3(TPB), 0, st, ends, lists, list_stride, bases,
+                       buckets, W, B);
+}
+void l_reduce_segments(hipStream_t st, const uint32_t* buckets, int W, uint32_t B, uint32_t L, uint32_t* out) {
+    hipLaunchKernelGGL(k_reduce_segments, dim3(blocks_for((size_t)W * (B / L), 64)), dim3(64), 0, st, buckets, W, B, L, out);
+}
+void l_sum_level(hipStream_t st, const uint32_t* in, int W, uint32_t M, uint32_t L, uint32_t* out) {
+    const uint32_t Mo = (M + L - 1) / L;
+    hipLaunchKernelGGL(k_sum_level, dim3(blocks_for((size_t)W * Mo, 64)), dim3(64), 0, st, in, W, M, L, out);
+}
+void l_horner(hipStream_t st, const uint32_t* window_sums, int W, int c, int form, uint32_t* out) {
+    hipLaunchKernelGGL(k_horner, dim3(1), dim3(64), 0, st, window_sums, W, c, form, out);
+}
+void l_sum_points(hipStream_t st, const uint32_t* pts, int k, int form, uint32_t* out) {
+    hipLaunchKernelGGL(k_sum_points, dim3(1), dim3(64), 0, st, pts, k, form, out);
+}
+void l_gen_bases_seq(hipStream_t st, unsigned long long first, size_t n, uint32_t* dst) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_gen_bases_seq, dim3(blocks_for(n)), dim3(TPB), 0, st, first, n, dst);
+}
+void l_export_affine(hipStream_t st, const uint32_t* src, size_t n, uint32_t* dst) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_export_affine, dim3(blocks_for(n)), dim3(TPB), 0, st, src, n, dst);
+}
+void l_field_op(hipStream_t st, int op, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t n) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_field_op, dim3(blocks_for(n)), dim3(TPB), 0, st, op, a, b, out, n);
+}
+void l_group_op(hipStream_t st, int op, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t n, int form) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_group_op, dim3(blocks_for(n)), dim3(TPB), 0, st, op, a, b, out, n, form);
+}
+void l_digits(hipStream_t st, const uint32_t* scalars, size_t n, int mont, int c, int W, int32_t* out) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_digits, dim3(blocks_for(n)), dim3(TPB), 0, st, scalars, n, mont, c, W, out);
+}
+void l_mul_bench(hipStream_t st, uint32_t* inout, size_t nthreads, int iters, int inline_variant) {
+    if (!nthreads) return;
+#if AMDMSM_BENCH_BOTH
+    if (inline_variant) {
+        hipLaunchKernelGGL(k_mul_bench<true>, dim3(blocks_for(nthreads)), dim3(TPB), 0, st, inout, nthreads, iters);
+        return;
+    }
+#endif
+    hipLaunchKernelGGL(k_mul_bench<false>, dim3(blocks_for(nthreads)), dim3(TPB), 0, st, inout, nthreads, iters);
+}
+void l_madd_bench(hipStream_t st, const uint32_t* pts, uint32_t* out, size_t nthreads, int iters, int inline_variant) {
+    if (!nthreads) return;
+#if AMDMSM_BENCH_BOTH
+    if (inline_variant) {
+        hipLaunchKernelGGL(k_madd_bench<EI>, dim3(blocks_for(nthreads)), dim3(TPB), 0, st, pts, out, nthreads, iters);
+        return;
+    }
+#endif
+    hipLaunchKernelGGL(k_madd_bench<E>, dim3(blocks_for(nthreads)), dim3(TPB), 0, st, pts, out, nthreads, iters);
+}
+
+const group_vtable g_vt = {
+    GP::CURVE, GP::GROUP, FRW, EW, FR::BITS, GP::LIBFF_PROJECTIVE ? 1 : 0, FR::R,
+    l_import_bases, l_count, l_scatter, l_accumulate, l_reduce_segments, l_sum_level, l_horner, l_sum_points,
+    l_gen_bases_seq, l_export_affine, l_field_op, l_group_op, l_digits, l_mul_bench, l_madd_bench,
+};
+
+}  // namespace
+
+const group_vtable* AMDMSM_VT() { return &g_vt; }
+
+}  // namespace amdmsm

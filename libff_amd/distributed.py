@@ -1,0 +1,86 @@
+"""Range-sharded MSM across the GPUs of one node.
+
+libff::multi_exp already shards by contiguous input range and sums the partial
+results serially (multiexp.tcc:663-687: ``one = total / chunks``, the last chunk takes
+the remainder).  Here a chunk is a rank: one process per GPU, each rank reduces its
+range to ONE engine-Jacobian point on its own device, the partials are exchanged with
+a single all-gather (RCCL over xGMI; 3*coord bytes per rank, latency-bound) and every
+rank sums the world_size partials locally -- all-gather + local reduce = the
+"all-reduce of partial sums" (EC addition is not an RCCL reduction operator).
+
+The two callables make the exchange testable on CPU with the gloo backend
+(tests/test_distributed_cpu.py supplies oracle-backed ones); on a GPU box they default
+to the HIP engine.
+"""
+import numpy as np
+
+
+def shard_range(total, world_size, rank):
+    """Contiguous range of rank ``rank``: multiexp.tcc:663, 675-678."""
+    one = total // world_size
+    lo = rank * one
+    hi = total if rank == world_size - 1 else (rank + 1) * one
+    return lo, hi
+
+
+def all_gather_partials(partial_words, group=None):
+    """all-gather one partial point (1-D integer tensor) from every rank -> (world, words)."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    out = [torch.empty_like(partial_words) for _ in range(world)]
+    dist.all_gather(out, partial_words, group=group)
+    return torch.stack(out, dim=0)
+
+
+def sharded_multi_exp(local_msm, combine, group=None):
+    """Run ``local_msm()`` (this rank's partial, engine-Jacobian words as a torch tensor on
+    the rank's device), exchange, and return ``combine(stacked_partials)``."""
+    partial = local_msm()
+    stacked = all_gather_partials(partial, group=group)
+    return combine(stacked)
+
+
+class ShardedMsm:
+    """Device-resident sharded MSM for one (curve, group): each rank holds its own range of
+    compact-affine bases and Montgomery scalars in HBM as torch tensors."""
+
+    def __init__(self, engine, curve, group_id, process_group=None):
+        import torch
+
+        self.torch = torch
+        self.engine = engine
+        self.curve = curve
+        self.group_id = group_id
+        self.pg = process_group
+        from .engine import sizes
+
+        self.sz = sizes(curve, group_id)
+        dev = torch.device("cuda", engine.device)
+        self.partial = torch.zeros(self.sz["g_bytes"] // 8, dtype=torch.int64, device=dev)
+        self.result = torch.zeros(self.sz["g_bytes"] // 8, dtype=torch.int64, device=dev)
+
+    def run(self, bases_affine, scalars, n, out_form, window_bits=0):
+        """bases_affine / scalars: this rank's shard (torch tensors on its GPU)."""
+        from .engine import OUT_JACOBIAN
+
+        torch = self.torch
+        stream = torch.cuda.current_stream().cuda_stream
+        self.engine.msm_device(self.curve, self.group_id, bases_affine.data_ptr(), scalars.data_ptr(), n,
+                               self.partial.data_ptr(), out_form=OUT_JACOBIAN, window_bits=window_bits,
+                               stream=stream)
+        import torch.distributed as dist
+
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.pg) > 1:
+            stacked = all_gather_partials(self.partial, group=self.pg).contiguous()
+            k = stacked.shape[0]
+        else:
+            stacked, k = self.partial, 1
+        self.engine.sum_points_device(self.curve, self.group_id, stacked.data_ptr(), k, out_form,
+                                      self.result.data_ptr(), stream=stream)
+        return self.result
+
+
+def numpy_words(t):
+    return np.ascontiguousarray(t.detach().cpu().numpy()).view(np.uint64)

@@ -1,0 +1,375 @@
+"""ctypes binding of libamdmsm.so -- the host-side mirror of libff's multi_exp interface.
+
+The names follow the reference (libff/algebra/scalar_multiplication/multiexp.hpp:21-141):
+``multi_exp``, ``multi_exp_filter_one_zero``, ``batch_to_special``,
+``bdlo12_signed_optimal_c``, the ``multi_exp_method_*`` / ``multi_exp_base_form_*`` enums.
+Everything is computed by the HIP engine; there is NO CPU fallback here -- a missing
+``libamdmsm.so`` or a missing GPU raises immediately.
+
+Array conventions (numpy ``uint64``, libff's in-memory layout, see include/amdmsm.h):
+  scalars  (n, fr_limbs)      Montgomery residues (as ``std::vector<Fr>`` holds them)
+  bases    (n, 3*coord_limbs) (X, Y, Z) records
+  result   (3*coord_limbs,)   (X, Y, Z); ``out_form`` selects the representative
+"""
+import ctypes
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(HERE, "libamdmsm.so")
+
+# curve / group ids (include/amdmsm.h)
+ALT_BN128, BLS12_377, BW6_761 = 0, 1, 2
+G1, G2 = 1, 2
+CURVE_NAMES = {ALT_BN128: "alt_bn128", BLS12_377: "bls12_377", BW6_761: "bw6_761"}
+
+# libff::multi_exp_method, multiexp.hpp:21-43
+multi_exp_method_naive = 0
+multi_exp_method_naive_plain = 1
+multi_exp_method_bos_coster = 2
+multi_exp_method_BDLO12 = 3
+multi_exp_method_BDLO12_signed = 4
+# libff::multi_exp_base_form, multiexp.hpp:45-51
+multi_exp_base_form_normal = 0
+multi_exp_base_form_special = 1
+
+OUT_JACOBIAN, OUT_LIBFF, OUT_AFFINE = 0, 1, 2
+PH_COUNT, PH_SCATTER, PH_ACCUM, PH_REDUCE, PH_FINAL, PH_TOTAL = range(6)
+MAX_PHASES = 8
+
+EXPORTED_SYMBOLS = [
+    "amdmsm_device_count", "amdmsm_ctx_create", "amdmsm_ctx_destroy", "amdmsm_strerror",
+    "amdmsm_last_error", "amdmsm_sizes", "amdmsm_plan", "amdmsm_pippenger_optimal_c",
+    "amdmsm_bdlo12_signed_optimal_c", "amdmsm_multi_exp", "amdmsm_multi_exp_filter_one_zero",
+    "amdmsm_batch_to_special", "amdmsm_import_bases_device", "amdmsm_export_affine_device",
+    "amdmsm_msm_device", "amdmsm_sum_points_device", "amdmsm_gen_bases_seq_device",
+    "amdmsm_set_timing", "amdmsm_get_timings", "amdmsm_field_op_device", "amdmsm_group_op_device",
+    "amdmsm_digits_device", "amdmsm_mul_bench_device", "amdmsm_madd_bench_device", "amdmsm_malloc", "amdmsm_free",
+    "amdmsm_memcpy_h2d", "amdmsm_memcpy_d2h", "amdmsm_synchronize",
+]
+
+
+class AmdMsmError(RuntimeError):
+    pass
+
+
+class _Opts(ctypes.Structure):
+    _fields_ = [("window_bits", ctypes.c_int), ("segment_len", ctypes.c_int), ("out_form", ctypes.c_int),
+                ("scalars_plain", ctypes.c_int), ("stream", ctypes.c_void_p)]
+
+
+_lib = None
+
+
+def load_library():
+    """Load libamdmsm.so (in-tree).  Raises if it has not been built: no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise AmdMsmError(
+                f"{SO_PATH} is missing: build the HIP engine first (python -m libff_amd.build or "
+                "__graft_entry__.build()); libff_amd has no CPU implementation")
+        L = ctypes.CDLL(SO_PATH)
+        L.amdmsm_strerror.restype = ctypes.c_char_p
+        L.amdmsm_last_error.restype = ctypes.c_char_p
+        L.amdmsm_last_error.argtypes = [ctypes.c_void_p]
+        L.amdmsm_pippenger_optimal_c.restype = ctypes.c_size_t
+        L.amdmsm_bdlo12_signed_optimal_c.restype = ctypes.c_size_t
+        L.amdmsm_ctx_destroy.restype = None
+        L.amdmsm_ctx_destroy.argtypes = [ctypes.c_void_p]
+        _lib = L
+    return _lib
+
+
+def bdlo12_signed_optimal_c(num_entries):
+    """multiexp.hpp:53-57 / multiexp.tcc:637-641"""
+    return int(load_library().amdmsm_bdlo12_signed_optimal_c(ctypes.c_size_t(num_entries)))
+
+
+def pippenger_optimal_c(num_elements):
+    """multiexp.tcc:35-40"""
+    return int(load_library().amdmsm_pippenger_optimal_c(ctypes.c_size_t(num_elements)))
+
+
+def sizes(curve, group):
+    out = (ctypes.c_size_t * 4)()
+    rc = load_library().amdmsm_sizes(curve, group, out)
+    if rc:
+        raise AmdMsmError(f"amdmsm_sizes({curve},{group}): {rc}")
+    return {"fr_bytes": out[0], "g_bytes": out[1], "affine_bytes": out[2], "fr_bits": out[3]}
+
+
+def plan(curve, group, n, window_bits=0):
+    c, w = ctypes.c_int(0), ctypes.c_int(0)
+    b = ctypes.c_uint32(0)
+    ws = ctypes.c_size_t(0)
+    rc = load_library().amdmsm_plan(curve, group, ctypes.c_size_t(n), window_bits, ctypes.byref(c),
+                                    ctypes.byref(w), ctypes.byref(b), ctypes.byref(ws))
+    if rc:
+        raise AmdMsmError(f"amdmsm_plan: {rc}")
+    return {"c": c.value, "num_windows": w.value, "num_buckets": b.value, "workspace_bytes": ws.value}
+
+
+def _np_ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+class Engine:
+    """One amdmsm context (device, stream, workspace).  Fails loudly without a GPU."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        self.device = device
+        h = ctypes.c_void_p(None)
+        rc = self.lib.amdmsm_ctx_create(device, ctypes.byref(h))
+        if rc:
+            raise AmdMsmError("amdmsm_ctx_create(device=%d) failed: %s" %
+                              (device, self.lib.amdmsm_strerror(rc).decode()))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.amdmsm_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc:
+            raise AmdMsmError("%s failed: %s (%s)" % (what, self.lib.amdmsm_strerror(rc).decode(),
+                                                      self.lib.amdmsm_last_error(self.h).decode()))
+
+    def _opts(self, window_bits=0, segment_len=0, out_form=OUT_LIBFF, scalars_plain=False, stream=None):
+        return _Opts(window_bits, segment_len, out_form, int(scalars_plain), stream)
+
+    # ---------------------------------------------------------------- host API
+    def multi_exp(self, curve, group, bases, scalars, method=multi_exp_method_BDLO12_signed,
+                  base_form=multi_exp_base_form_normal, chunks=1, out_form=OUT_AFFINE, window_bits=0,
+                  scalars_plain=False):
+        """libff::multi_exp<G, Fr, Method, BaseForm>(bases, scalars, chunks), multiexp.tcc:643-688.
+
+        BDLO12 and BDLO12_signed both run the device Pippenger engine (the result is a
+        group element; it does not depend on the digit convention).  ``chunks`` > 1 takes
+        the reference's split-and-sum route: contiguous ranges (last one takes the
+        remainder), one partial per range, partials summed on the device.
+        """
+        if method not in (multi_exp_method_BDLO12, multi_exp_method_BDLO12_signed):
+            raise NotImplementedError("only the BDLO12 / BDLO12_signed methods run on the GPU engine")
+        bases = np.ascontiguousarray(bases, dtype=np.uint64)
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint64)
+        s = sizes(curve, group)
+        n = bases.shape[0] if bases.ndim == 2 else 0
+        if n:
+            assert bases.shape[1] * 8 == s["g_bytes"], "bases must be (n, 3*coord_limbs) uint64"
+            assert scalars.shape == (n, s["fr_bytes"] // 8), "scalars must be (n, fr_limbs) uint64"
+        out = np.zeros(s["g_bytes"] // 8, dtype=np.uint64)
+        total = n
+        if total < chunks or chunks == 1:
+            o = self._opts(window_bits=window_bits, out_form=out_form, scalars_plain=scalars_plain)
+            rc = self.lib.amdmsm_multi_exp(self.h, curve, group, _np_ptr(bases) if n else None,
+                                           ctypes.c_size_t(s["g_bytes"]), base_form,
+                                           _np_ptr(scalars) if n else None, ctypes.c_size_t(n), _np_ptr(out),
+                                           ctypes.byref(o))
+            self._check(rc, "amdmsm_multi_exp")
+            return out
+        one = total // chunks
+        partials = np.zeros((chunks, s["g_bytes"] // 8), dtype=np.uint64)
+        o = self._opts(window_bits=window_bits, out_form=OUT_JACOBIAN, scalars_plain=scalars_plain)
+        for i in range(chunks):
+            lo = i * one
+            hi = total if i == chunks - 1 else (i + 1) * one
+            b, sc = bases[lo:hi], scalars[lo:hi]
+            rc = self.lib.amdmsm_multi_exp(self.h, curve, group, _np_ptr(b), ctypes.c_size_t(s["g_bytes"]),
+                                           base_form, _np_ptr(sc), ctypes.c_size_t(hi - lo),
+                                           _np_ptr(partials[i]), ctypes.byref(o))
+            self._check(rc, "amdmsm_multi_exp")
+        return self.sum_points(curve, group, partials, out_form=out_form)
+
+    def multi_exp_filter_one_zero(self, curve, group, bases, scalars, method=multi_exp_method_BDLO12_signed,
+                                  base_form=multi_exp_base_form_normal, chunks=1, out_form=OUT_AFFINE,
+                                  scalars_plain=False):
+        """libff::multi_exp_filter_one_zero, multiexp.tcc:690-757.  Returns (result, stats)."""
+        if method not in (multi_exp_method_BDLO12, multi_exp_method_BDLO12_signed):
+            raise NotImplementedError("only the BDLO12 / BDLO12_signed methods run on the GPU engine")
+        bases = np.ascontiguousarray(bases, dtype=np.uint64)
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint64)
+        s = sizes(curve, group)
+        n = bases.shape[0]
+        out = np.zeros(s["g_bytes"] // 8, dtype=np.uint64)
+        stats = (ctypes.c_size_t * 3)()
+        o = self._opts(out_form=out_form, scalars_plain=scalars_plain)
+        rc = self.lib.amdmsm_multi_exp_filter_one_zero(
+            self.h, curve, group, _np_ptr(bases), ctypes.c_size_t(s["g_bytes"]), base_form, _np_ptr(scalars),
+            ctypes.c_size_t(n), _np_ptr(out), ctypes.byref(o), stats)
+        self._check(rc, "amdmsm_multi_exp_filter_one_zero")
+        return out, {"skipped": stats[0], "ones": stats[1], "other": stats[2]}
+
+    def batch_to_special(self, curve, group, elems):
+        """libff::batch_to_special<G>, multiexp.tcc:949-974 (returns a converted copy)."""
+        elems = np.ascontiguousarray(elems, dtype=np.uint64).copy()
+        s = sizes(curve, group)
+        rc = self.lib.amdmsm_batch_to_special(self.h, curve, group, _np_ptr(elems), ctypes.c_size_t(s["g_bytes"]),
+                                              ctypes.c_size_t(elems.shape[0]))
+        self._check(rc, "amdmsm_batch_to_special")
+        return elems
+
+    def sum_points(self, curve, group, points_jacobian, out_form=OUT_AFFINE):
+        """Sum of engine-Jacobian partial results (the serial tail of multiexp.tcc:681-687)."""
+        pts = np.ascontiguousarray(points_jacobian, dtype=np.uint64)
+        s = sizes(curve, group)
+        k = pts.shape[0]
+        d_pts, d_out = self.malloc(max(1, pts.nbytes)), self.malloc(s["g_bytes"])
+        try:
+            if k:
+                self.h2d(d_pts, pts)
+            rc = self.lib.amdmsm_sum_points_device(self.h, curve, group, d_pts, k, out_form, d_out, None)
+            self._check(rc, "amdmsm_sum_points_device")
+            out = np.zeros(s["g_bytes"] // 8, dtype=np.uint64)
+            self.d2h(out, d_out)
+            return out
+        finally:
+            self.free(d_pts)
+            self.free(d_out)
+
+    # -------------------------------------------------------- raw device API
+    def malloc(self, nbytes):
+        p = ctypes.c_void_p(None)
+        self._check(self.lib.amdmsm_malloc(self.h, ctypes.c_size_t(nbytes), ctypes.byref(p)), "amdmsm_malloc")
+        return p
+
+    def free(self, p):
+        self._check(self.lib.amdmsm_free(self.h, p), "amdmsm_free")
+
+    def h2d(self, d_ptr, arr):
+        arr = np.ascontiguousarray(arr)
+        self._check(self.lib.amdmsm_memcpy_h2d(self.h, d_ptr, _np_ptr(arr), ctypes.c_size_t(arr.nbytes)), "h2d")
+
+    def d2h(self, arr, d_ptr):
+        assert arr.flags["C_CONTIGUOUS"]
+        self._check(self.lib.amdmsm_memcpy_d2h(self.h, _np_ptr(arr), d_ptr, ctypes.c_size_t(arr.nbytes)), "d2h")
+
+    def synchronize(self):
+        self._check(self.lib.amdmsm_synchronize(self.h), "amdmsm_synchronize")
+
+    def import_bases_device(self, curve, group, d_src_xyz, stride_bytes, base_form, n, d_dst_affine, stream=None):
+        self._check(self.lib.amdmsm_import_bases_device(self.h, curve, group, ctypes.c_void_p(d_src_xyz),
+                                                        ctypes.c_size_t(stride_bytes), base_form,
+                                                        ctypes.c_size_t(n), ctypes.c_void_p(d_dst_affine),
+                                                        ctypes.c_void_p(stream)), "amdmsm_import_bases_device")
+
+    def export_affine_device(self, curve, group, d_src_affine, n, d_dst_xyz, stream=None):
+        self._check(self.lib.amdmsm_export_affine_device(self.h, curve, group, ctypes.c_void_p(d_src_affine),
+                                                         ctypes.c_size_t(n), ctypes.c_void_p(d_dst_xyz),
+                                                         ctypes.c_void_p(stream)), "amdmsm_export_affine_device")
+
+    def msm_device(self, curve, group, d_bases_affine, d_scalars, n, d_out_xyz, out_form=OUT_LIBFF,
+                   window_bits=0, segment_len=0, scalars_plain=False, stream=None):
+        o = self._opts(window_bits, segment_len, out_form, scalars_plain, stream)
+        self._check(self.lib.amdmsm_msm_device(self.h, curve, group, ctypes.c_void_p(d_bases_affine),
+                                               ctypes.c_void_p(d_scalars), ctypes.c_size_t(n),
+                                               ctypes.c_void_p(d_out_xyz), ctypes.byref(o)), "amdmsm_msm_device")
+
+    def sum_points_device(self, curve, group, d_points, k, out_form, d_out, stream=None):
+        self._check(self.lib.amdmsm_sum_points_device(self.h, curve, group, ctypes.c_void_p(d_points), k, out_form,
+                                                      ctypes.c_void_p(d_out), ctypes.c_void_p(stream)),
+                    "amdmsm_sum_points_device")
+
+    def gen_bases_seq_device(self, curve, group, first, n, d_dst_affine, stream=None):
+        self._check(self.lib.amdmsm_gen_bases_seq_device(self.h, curve, group, ctypes.c_uint64(first),
+                                                         ctypes.c_size_t(n), ctypes.c_void_p(d_dst_affine),
+                                                         ctypes.c_void_p(stream)), "amdmsm_gen_bases_seq_device")
+
+    def set_timing(self, enable=True):
+        self._check(self.lib.amdmsm_set_timing(self.h, int(enable)), "amdmsm_set_timing")
+
+    def get_timings(self):
+        ms = (ctypes.c_float * MAX_PHASES)()
+        self._check(self.lib.amdmsm_get_timings(self.h, ms), "amdmsm_get_timings")
+        return {"count_ms": ms[PH_COUNT], "scatter_ms": ms[PH_SCATTER], "accumulate_ms": ms[PH_ACCUM],
+                "reduce_ms": ms[PH_REDUCE], "final_ms": ms[PH_FINAL], "total_ms": ms[PH_TOTAL]}
+
+    # ------------------------------------------------------------ test hooks
+    def _dev_arrays(self, *arrs):
+        ptrs = []
+        for a in arrs:
+            if a is None:
+                ptrs.append(None)
+                continue
+            p = self.malloc(max(16, a.nbytes))
+            self.h2d(p, a)
+            ptrs.append(p)
+        return ptrs
+
+    def field_op(self, curve, group, op, a, b=None):
+        """coordinate-field op over arrays: 0 mul 1 sqr 2 add 3 sub 4 neg 5 inverse"""
+        a = np.ascontiguousarray(a, dtype=np.uint64)
+        b = np.ascontiguousarray(b, dtype=np.uint64) if b is not None else None
+        out = np.zeros_like(a)
+        pa, pb, po = self._dev_arrays(a, b, out)
+        try:
+            self._check(self.lib.amdmsm_field_op_device(self.h, curve, group, op, pa, pb, po,
+                                                        ctypes.c_size_t(a.shape[0])), "amdmsm_field_op_device")
+            self.d2h(out, po)
+        finally:
+            for p in (pa, pb, po):
+                if p is not None:
+                    self.free(p)
+        return out
+
+    def group_op(self, curve, group, op, a, b=None, out_form=OUT_LIBFF):
+        """group op over arrays of libff records: 0 add 1 mixed_add 2 dbl"""
+        a = np.ascontiguousarray(a, dtype=np.uint64)
+        b = np.ascontiguousarray(b, dtype=np.uint64) if b is not None else None
+        out = np.zeros_like(a)
+        pa, pb, po = self._dev_arrays(a, b, out)
+        try:
+            self._check(self.lib.amdmsm_group_op_device(self.h, curve, group, op, pa, pb, po,
+                                                        ctypes.c_size_t(a.shape[0]), out_form),
+                        "amdmsm_group_op_device")
+            self.d2h(out, po)
+        finally:
+            for p in (pa, pb, po):
+                if p is not None:
+                    self.free(p)
+        return out
+
+    def signed_digits(self, curve, scalars, c, num_windows, scalars_plain=False):
+        """device recoding of every scalar: int32 (n, num_windows), least-significant window first"""
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint64)
+        n = scalars.shape[0]
+        out = np.zeros((n, num_windows), dtype=np.int32)
+        ps, po = self._dev_arrays(scalars, out)
+        try:
+            self._check(self.lib.amdmsm_digits_device(self.h, curve, G1, ps, ctypes.c_size_t(n), int(scalars_plain),
+                                                      c, num_windows, po), "amdmsm_digits_device")
+            self.d2h(out, po)
+        finally:
+            self.free(ps)
+            self.free(po)
+        return out
+
+    def gen_bases_seq(self, curve, group, n, first=0, as_xyz=True):
+        """(first+i+1)*G for i < n, computed on the device; libff special-form records by default"""
+        s = sizes(curve, group)
+        d_aff = self.malloc(max(16, n * s["affine_bytes"]))
+        try:
+            self.gen_bases_seq_device(curve, group, first, n, d_aff.value)
+            if not as_xyz:
+                out = np.zeros((n, s["affine_bytes"] // 8), dtype=np.uint64)
+                self.d2h(out, d_aff)
+                return out
+            d_xyz = self.malloc(max(16, n * s["g_bytes"]))
+            try:
+                self.export_affine_device(curve, group, d_aff.value, n, d_xyz.value)
+                out = np.zeros((n, s["g_bytes"] // 8), dtype=np.uint64)
+                self.d2h(out, d_xyz)
+                return out
+            finally:
+                self.free(d_xyz)
+        finally:
+            self.free(d_aff)

@@ -1137,6 +1137,20 @@ int orc_fr_as_bigint(int curve, const uint64_t *mont, uint64_t *plain)
     fp_from_mont(g->fr, plain, mont);
     return 0;
 }
+int orc_fr_as_bigint_n(int curve, size_t n, const uint64_t *mont, uint64_t *plain)
+{
+    const orc_group *g = find_group(curve, 1);
+    if (!g) return -2;
+    for (size_t i = 0; i < n; ++i) fp_from_mont(g->fr, plain + i * g->fr->n, mont + i * g->fr->n);
+    return 0;
+}
+int orc_fr_from_bigint_n(int curve, size_t n, const uint64_t *plain, uint64_t *mont)
+{
+    const orc_group *g = find_group(curve, 1);
+    if (!g) return -2;
+    for (size_t i = 0; i < n; ++i) fp_to_mont(g->fr, mont + i * g->fr->n, plain + i * g->fr->n);
+    return 0;
+}
 int orc_fr_from_bigint(int curve, const uint64_t *plain, uint64_t *mont)
 {
     const orc_group *g = find_group(curve, 1);

@@ -53,6 +53,8 @@ int orc_fq_op(int curve, int group, int op, const uint64_t *a, const uint64_t *b
 int orc_scalar_mul(int curve, int group, const uint64_t *base, const uint64_t *scalar_mont, uint64_t *out);
 int orc_fr_as_bigint(int curve, const uint64_t *mont, uint64_t *plain);
 int orc_fr_from_bigint(int curve, const uint64_t *plain, uint64_t *mont);
+int orc_fr_as_bigint_n(int curve, size_t n, const uint64_t *mont, uint64_t *plain);
+int orc_fr_from_bigint_n(int curve, size_t n, const uint64_t *plain, uint64_t *mont);
 long orc_signed_digit(int curve, const uint64_t *plain, size_t c, size_t idx);
 long orc_digit(int curve, const uint64_t *plain, size_t c, size_t idx);
 int orc_group_consts(int curve, int group, uint64_t *one, uint64_t *zero);

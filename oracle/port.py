@@ -126,12 +126,20 @@ def _rowwise(fn, curve, arr):
     return out
 
 
+def _batch(fn, curve, arr):
+    arr = _u64(arr)
+    out = np.zeros_like(arr)
+    n = arr.size // arr.shape[-1]
+    assert fn(curve, ctypes.c_size_t(n), _p(arr), _p(out)) == 0
+    return out
+
+
 def fr_as_bigint(curve, mont):
-    return _rowwise(lib().orc_fr_as_bigint, curve, mont)
+    return _batch(lib().orc_fr_as_bigint_n, curve, mont)
 
 
 def fr_from_bigint(curve, plain):
-    return _rowwise(lib().orc_fr_from_bigint, curve, plain)
+    return _batch(lib().orc_fr_from_bigint_n, curve, plain)
 
 
 def signed_digit(curve, plain, c, idx):

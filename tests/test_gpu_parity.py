@@ -1,0 +1,233 @@
+"""GPU parity tests proper: the HIP engine, called through the C ABI (libff_amd.Engine is a
+ctypes veneer over include/amdmsm.h), against
+
+  * the golden fixtures generated from the reference (tests/golden/),
+  * the C restatement (oracle/) on the same seeded inputs at sizes it finishes in seconds,
+  * size-independent properties at BASELINE.json's full size (2^20 points).
+
+Bar: bit-exact.  The MSM result is a group element, so results are compared in affine
+form (libff to_affine_coordinates) where the coordinates are canonical field elements;
+field ops and Jacobian group ops are compared limb for limb.
+"""
+import numpy as np
+import pytest
+
+from common import DIGIT_CS, GROUPS, MSM_SIZES, golden, literal, small_scalars_mont, to_int
+
+pytestmark = pytest.mark.gpu
+
+import libff_amd  # noqa: E402
+from libff_amd import (OUT_AFFINE, OUT_LIBFF, multi_exp_base_form_normal, multi_exp_base_form_special,  # noqa: E402
+                       multi_exp_method_BDLO12, multi_exp_method_BDLO12_signed)
+
+JACOBIAN_GROUPS = [g for g in GROUPS if g[1] != 2]
+
+
+@pytest.mark.parametrize("name,curve,group", GROUPS)
+def test_field_ops_match_reference(engine, name, curve, group):
+    g = golden()
+    a, b = g[f"{name}/fq_a"], g[f"{name}/fq_b"]
+    for opname, op in (("mul", 0), ("sqr", 1), ("add", 2), ("sub", 3), ("neg", 4), ("inv", 5)):
+        got = engine.field_op(curve, group, op, a, b if op in (0, 2, 3) else None)
+        assert (got == g[f"{name}/fq_{opname}"]).all(), opname
+
+
+@pytest.mark.parametrize("name,curve,group", GROUPS)
+def test_group_ops_match_reference(engine, name, curve, group):
+    g = golden()
+    A, B, Bs = g[f"{name}/g_a"], g[f"{name}/g_b"], g[f"{name}/g_b_special"]
+    # canonical (affine) comparison for every group, incl. P+P, P+(-P), P+0, 0+P, 0+0
+    assert (engine.group_op(curve, group, 0, A, B, OUT_AFFINE) == g[f"{name}/g_add_affine"]).all()
+    assert (engine.group_op(curve, group, 1, A, Bs, OUT_AFFINE) == g[f"{name}/g_madd_affine"]).all()
+    assert (engine.group_op(curve, group, 2, A, None, OUT_AFFINE) == g[f"{name}/g_dbl_affine"]).all()
+    if curve != 2:
+        # Jacobian groups use libff's own formulas: identical (X, Y, Z) limbs wherever the
+        # reference result is not the point at infinity (whose X, Y are unconstrained)
+        for op, second, key in ((0, B, "g_add"), (1, Bs, "g_madd"), (2, None, "g_dbl")):
+            got = engine.group_op(curve, group, op, A, second, OUT_LIBFF)
+            want = g[f"{name}/{key}"]
+            el = want.shape[1] // 3
+            finite = np.array([to_int(w[2 * el:]) != 0 for w in want])
+            assert (got[finite] == want[finite]).all(), key
+
+
+@pytest.mark.parametrize("name,curve,group", [x for x in GROUPS if x[2] == 1])
+def test_signed_digits_match_reference(engine, port, name, curve, group):
+    g = golden()
+    plain = g[f"{name}/digit_scalars_plain"]
+    bits = libff_amd.sizes(curve, 1)["fr_bits"]
+    for c in DIGIT_CS:
+        nd = (bits + 2 + c - 1) // c
+        got = engine.signed_digits(curve, plain, c, nd, scalars_plain=True)
+        assert (got == g[f"{name}/signed_digits_c{c}"]).all(), c
+    # Montgomery input path (as_bigint on the device) against the oracle
+    sc = port.scalars_sha512(curve, 4242, 200)
+    plain = port.fr_as_bigint(curve, sc)
+    for c in (4, 13, 16, 20):
+        nd = (bits + 2 + c - 1) // c
+        got = engine.signed_digits(curve, sc, c, nd)
+        want = np.array([[port.signed_digit(curve, plain[i], c, k) for k in range(nd)] for i in range(0, 200, 17)])
+        assert (got[::17] == want).all(), c
+
+
+@pytest.mark.parametrize("name,curve,group", GROUPS)
+def test_multi_exp_small_like_reference_tests(engine, port, name, curve, group):
+    """test_multiexp.cpp:205-284: bases [i+1]G, scalars n-i, methods x forms x n x chunks."""
+    g = golden()
+    for n in MSM_SIZES:
+        bases = port.bases_seq(curve, group, n)
+        scalars = small_scalars_mont(port, curve, [n - i for i in range(n)])
+        want = g[f"{name}/msm_small_{n}"]
+        for method in (multi_exp_method_BDLO12_signed, multi_exp_method_BDLO12):
+            for form in (multi_exp_base_form_normal, multi_exp_base_form_special):
+                for chunks in (1, 2, 4):
+                    got = engine.multi_exp(curve, group, bases, scalars, method, form, chunks)
+                    assert (got == want).all(), (n, method, form, chunks)
+
+
+@pytest.mark.parametrize("name,curve,group", GROUPS)
+def test_multi_exp_golden_vectors(engine, port, name, curve, group):
+    g = golden()
+    bases, scalars = g[f"{name}/msm_sha256_bases"], g[f"{name}/msm_sha256_scalars"]
+    want = g[f"{name}/msm_sha256"]
+    assert (engine.multi_exp(curve, group, bases, scalars, base_form=multi_exp_base_form_special) == want).all()
+    assert (engine.multi_exp(curve, group, bases, scalars, base_form=multi_exp_base_form_normal, chunks=3) == want).all()
+    # window size must not change the group element
+    for c in (2, 5, 9, 12):
+        got = engine.multi_exp(curve, group, bases, scalars, base_form=multi_exp_base_form_special, window_bits=c)
+        assert (got == want).all(), c
+    # bases in normal (non-affine) form
+    nb = g[f"{name}/msm_normal16_bases"]
+    got = engine.multi_exp(curve, group, nb, scalars[:16], base_form=multi_exp_base_form_normal)
+    assert (got == g[f"{name}/msm_normal16"]).all()
+    # larger golden results, inputs regenerated by the (pinned) generators
+    big = literal()["groups"][name]["big_n"]
+    sc = port.scalars_sha512(curve, 0, big)
+    got = engine.multi_exp(curve, group, port.bases_seq(curve, group, big), sc, base_form=multi_exp_base_form_special)
+    assert (got == g[f"{name}/msm_sha_seq_{big}"]).all()
+    # profiler-style bases: 32 distinct points repeated -> P == Q collisions inside buckets
+    got = engine.multi_exp(curve, group, port.bases_r32(curve, group, big), sc, base_form=multi_exp_base_form_special)
+    assert (got == g[f"{name}/msm_sha_r32_{big}"]).all()
+
+
+@pytest.mark.parametrize("name,curve,group", GROUPS)
+def test_filter_one_zero(engine, port, name, curve, group):
+    g = golden()
+    scalars = g[f"{name}/msm_filter64_scalars"]
+    bases = port.bases_seq(curve, group, 64)
+    got, stats = engine.multi_exp_filter_one_zero(curve, group, bases, scalars,
+                                                  base_form=multi_exp_base_form_special)
+    assert (got == g[f"{name}/msm_filter64"]).all()
+    assert [stats["skipped"], stats["ones"], stats["other"]] == literal()["groups"][name]["filter64_counts"]
+
+
+def test_edge_case_1(engine):
+    """test_multiexp.cpp:344-390 literal vector."""
+    g = golden()
+    got = engine.multi_exp(0, 1, g["alt_bn128_g1/edge1_bases"], g["alt_bn128_g1/edge1_scalars"],
+                           base_form=multi_exp_base_form_normal)
+    assert (got == g["alt_bn128_g1/edge1_result"]).all()
+    for c in (2, 3, 11, 19):
+        got = engine.multi_exp(0, 1, g["alt_bn128_g1/edge1_bases"], g["alt_bn128_g1/edge1_scalars"],
+                               base_form=multi_exp_base_form_normal, window_bits=c)
+        assert (got == g["alt_bn128_g1/edge1_result"]).all(), c
+
+
+@pytest.mark.parametrize("name,curve,group", GROUPS)
+def test_degenerate_inputs(engine, port, name, curve, group):
+    one, zero = port.group_consts(curve, group)
+    s = libff_amd.sizes(curve, group)
+    # empty input -> zero
+    empty_b = np.zeros((0, s["g_bytes"] // 8), dtype=np.uint64)
+    empty_s = np.zeros((0, s["fr_bytes"] // 8), dtype=np.uint64)
+    assert (engine.multi_exp(curve, group, empty_b, empty_s) == zero).all()
+    # all-zero scalars -> zero; zero bases are ignored
+    bases = port.bases_seq(curve, group, 9)
+    zs = np.zeros((9, s["fr_bytes"] // 8), dtype=np.uint64)
+    assert (engine.multi_exp(curve, group, bases, zs, base_form=multi_exp_base_form_special) == zero).all()
+    sc = port.scalars_sha512(curve, 50, 9)
+    bz = bases.copy()
+    bz[2] = zero
+    bz[7] = zero
+    want = port.multi_exp(curve, group, bz, sc, port.BDLO12_SIGNED, 1)
+    assert (engine.multi_exp(curve, group, bz, sc, base_form=multi_exp_base_form_special) == want).all()
+    assert (engine.multi_exp(curve, group, bz, sc, base_form=multi_exp_base_form_normal) == want).all()
+    # P and -P with the same scalar cancel: result zero out of non-trivial buckets
+    pair = np.stack([bases[0], port.group_op(curve, group, 3, bases[0])])
+    sc2 = np.stack([sc[0], sc[0]])
+    assert (engine.multi_exp(curve, group, pair, sc2, base_form=multi_exp_base_form_special) == zero).all()
+    # single element == scalar multiplication (curve_utils.tcc:14-32)
+    want = port.group_op(curve, group, 4, port.scalar_mul(curve, group, bases[3], sc[3]))
+    assert (engine.multi_exp(curve, group, bases[3:4], sc[3:4], base_form=multi_exp_base_form_special) == want).all()
+
+
+@pytest.mark.parametrize("name,curve,group", GROUPS)
+def test_batch_to_special_and_generators(engine, port, name, curve, group):
+    g = golden()
+    nb = g[f"{name}/msm_normal16_bases"]
+    assert (engine.batch_to_special(curve, group, nb) == port.batch_to_special(curve, group, nb)).all()
+    assert (engine.gen_bases_seq(curve, group, 40, first=0) == port.bases_seq(curve, group, 40)).all()
+    assert (engine.gen_bases_seq(curve, group, 5, first=(1 << 33) + 7) ==
+            port.bases_seq(curve, group, 5, first=(1 << 33) + 7)).all()
+
+
+@pytest.mark.parametrize("name,curve,group,n", [("alt_bn128_g1", 0, 1, 1 << 12), ("alt_bn128_g1", 0, 1, 6000),
+                                                 ("bls12_377_g1", 1, 1, 3000), ("alt_bn128_g2", 0, 2, 1500),
+                                                 ("bls12_377_g2", 1, 2, 800), ("bw6_761_g1", 2, 1, 800),
+                                                 ("bw6_761_g2", 2, 2, 500)])
+def test_multi_exp_matches_oracle_seeded(engine, port, name, curve, group, n):
+    """configs[0] (2^12 alt_bn128 G1) and ragged sizes for the other groups, oracle on the
+    same seeded inputs (SHA512_rng scalars; SEQ and R32 bases)."""
+    sc = port.scalars_sha512(curve, 31337, n)
+    for bases in (port.bases_seq(curve, group, n, first=11), port.bases_r32(curve, group, n)):
+        want = port.multi_exp(curve, group, bases, sc, port.BDLO12_SIGNED, 1, chunks=8, omp=True)
+        got = engine.multi_exp(curve, group, bases, sc, multi_exp_method_BDLO12_signed, multi_exp_base_form_special)
+        assert (got == want).all()
+        got = engine.multi_exp(curve, group, bases, sc, multi_exp_method_BDLO12, multi_exp_base_form_normal, chunks=3)
+        assert (got == want).all()
+
+
+def _closed_form_scalar(port, curve, scalars_mont, first):
+    """sum_i s_i * (first + i + 1) mod r, from Montgomery scalars, in Python integers."""
+    plain = port.fr_as_bigint(curve, scalars_mont)
+    n, fl = plain.shape
+    r = to_int(golden()[f"{libff_amd.engine.CURVE_NAMES[curve]}_g1/fr_modulus"])
+    lo32 = (plain & np.uint64(0xFFFFFFFF)).astype(np.uint64)
+    hi32 = (plain >> np.uint64(32)).astype(np.uint64)
+    total = 0
+    blk = 512   # 2^32 * 2^27 * 2^9 < 2^64 per block-column sum
+    for b0 in range(0, n, blk):
+        w = np.arange(first + b0 + 1, first + min(b0 + blk, n) + 1, dtype=np.uint64)[:, None]
+        lo = (lo32[b0:b0 + blk] * w).sum(axis=0)
+        hi = (hi32[b0:b0 + blk] * w).sum(axis=0)
+        for j in range(fl):
+            total += (int(lo[j]) << (64 * j)) + (int(hi[j]) << (64 * j + 32))
+    return total % r
+
+
+@pytest.mark.parametrize("name,curve,group,log2n", [("alt_bn128_g1", 0, 1, 20), ("bls12_377_g1", 1, 1, 18),
+                                                     ("bw6_761_g1", 2, 1, 16), ("bls12_377_g2", 1, 2, 16)])
+def test_full_size_closed_form_and_sharding(engine, port, name, curve, group, log2n):
+    """BASELINE configs at full size (2^20 alt_bn128 G1): the reference's own test pattern
+    (test_multiexp.cpp:205-256) -- bases [i+1]G so that the expected value is the closed
+    form (sum_i s_i (i+1)) * G -- with SHA512_rng scalars; plus window-size independence
+    and range sharding (multiexp.tcc:663-687) == unsharded."""
+    n = 1 << log2n
+    first = 0
+    sc = port.scalars_sha512(curve, 0, n)
+    bases = engine.gen_bases_seq(curve, group, n, first=first)      # device-generated, spot-checked below
+    for i in (0, 1, n // 3, n - 1):
+        assert (bases[i] == port.bases_seq(curve, group, 1, first=first + i)[0]).all()
+    k = _closed_form_scalar(port, curve, sc, first)
+    fl = sc.shape[1]
+    k_plain = np.array([[(k >> (64 * j)) & 0xFFFFFFFFFFFFFFFF for j in range(fl)]], dtype=np.uint64)
+    k_mont = port.fr_from_bigint(curve, k_plain)[0]
+    one, _ = port.group_consts(curve, group)
+    want = port.group_op(curve, group, 4, port.scalar_mul(curve, group, one, k_mont))
+    got = engine.multi_exp(curve, group, bases, sc, base_form=multi_exp_base_form_special)
+    assert (got == want).all()
+    auto_c = libff_amd.plan(curve, group, n)["c"]
+    got = engine.multi_exp(curve, group, bases, sc, base_form=multi_exp_base_form_special, window_bits=auto_c - 3)
+    assert (got == want).all()
+    got = engine.multi_exp(curve, group, bases, sc, base_form=multi_exp_base_form_special, chunks=8)
+    assert (got == want).all()

@@ -161,9 +161,9 @@ def emit_device_header():
             w(f"    static constexpr int DEG = {deg};           // coordinate field = Fq^DEG")
             w(f"    static constexpr bool LIBFF_PROJECTIVE = {'true' if c['coords'] == 'projective' else 'false'};"
               "  // libff in-memory coords are homogeneous projective")
+            w(f"    static constexpr int NR_SMALL = {g.get('nr', 0)};     // Fq2 = Fq[u]/(u^2 - NR); 0 when DEG == 1")
             if deg == 2:
                 nr = g["nr"] % c["q"]
-                w(f"    static constexpr int NR_SMALL = {g['nr']};     // Fq2 = Fq[u]/(u^2 - NR)")
                 w(f"    static constexpr uint32_t NR_MONT[{n}] = "
                   f"{c_arr(limbs(nr * fq['R'] % c['q'], n, 32), '0x%08xu')};")
             for coord in ("x", "y", "b"):
