@@ -242,6 +242,19 @@ AMDMSM_DEV void fp_to_mont(Fp<P, I>& r, const Fp<P, I>& a) {   // Fp_model(bigin
     fp_mul(r, a, r2);
 }
 
+// limb k of (p - 2), with the borrow propagated (bls12_377's q has p[0] == 1)
+template <class P>
+AMDMSM_DEV constexpr uint32_t fp_pm2_limb(int k) {
+    uint64_t borrow = 2;
+    uint32_t r = 0;
+    for (int i = 0; i <= k; ++i) {
+        const uint64_t d = (uint64_t)P::P[i] - borrow;
+        r = (uint32_t)d;
+        borrow = (d >> 63) & 1u;
+    }
+    return r;
+}
+
 // a^(p-2) (Fermat).  libff uses mpn_gcdext (fp.tcc:679-727); same field element.
 // Only used off the hot path (affine output, batch normalisation: one per thread).
 template <class P, bool I>
@@ -249,17 +262,13 @@ AMDMSM_DEV void fp_inv(Fp<P, I>& r, const Fp<P, I>& a) {
     constexpr int N = P::N;
     Fp<P, I> acc;
     fp_set_one(acc);
-    // exponent = p - 2, scanned MSB first; p is odd and p[0] >= 3 for our moduli
+    // exponent = p - 2, scanned MSB first
     for (int i = N * 32 - 1; i >= 0; --i) {
-        uint32_t w = P::P[0];
         // select limb i/32 of (p - 2) without a runtime-indexed private array
         const int li = i >> 5;
+        uint32_t w = 0;
 #pragma unroll
-        for (int k = 0; k < N; ++k) {
-            uint32_t pk = P::P[k];
-            if (k == 0) pk -= 2u;   // no borrow: p[0] >= 2
-            w = (li == k) ? pk : w;
-        }
+        for (int k = 0; k < N; ++k) w = (li == k) ? fp_pm2_limb<P>(k) : w;
         fp_sqr(acc, acc);
         if ((w >> (i & 31)) & 1u) fp_mul(acc, acc, a);
     }
