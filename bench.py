@@ -125,6 +125,8 @@ def main():
     ap.add_argument("--group", type=int, default=1, choices=(1, 2))
     ap.add_argument("--window-bits", type=int, default=0)
     ap.add_argument("--cpu-sample-log2n", type=int, default=18)
+    ap.add_argument("--extra-log2n", type=int, default=int(os.environ.get("AMDMSM_BENCH_EXTRA_LOG2N", "26")),
+                    help="also time this size after the main region (reported under 'also'); 0 disables")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -187,6 +189,39 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    # ---- second size of the metric (2^26 by default), outside the main timed region ----
+    also = None
+    if args.extra_log2n and args.extra_log2n != args.log2n:
+        n2 = 1 << args.extra_log2n
+        del bases, scalars
+        torch.cuda.empty_cache()
+        bases2 = torch.empty((n2, sz["affine_bytes"] // 8), dtype=torch.int64, device=dev)
+        eng.gen_bases_seq_device(curve, group, rank * n2, n2, bases2.data_ptr(), stream=stream)
+        scalars2 = random_scalars(curve, n2, dev, seed=4321 + rank)
+        torch.cuda.synchronize()
+        msm.run(bases2, scalars2, n2, libff_amd.OUT_LIBFF)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        k2 = 3
+        t1 = time.perf_counter()
+        for _ in range(k2):
+            msm.run(bases2, scalars2, n2, libff_amd.OUT_LIBFF)
+            ph2 = eng.get_timings()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        e2 = time.perf_counter() - t1
+        if world > 1:
+            tt = torch.tensor([e2], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            e2 = float(tt.item())
+        p2 = libff_amd.plan(curve, group, n2)
+        also = {"workload": f"{args.curve} G{group} MSM, 2^{args.extra_log2n} points per GPU", "steps": k2,
+                "value": n2 * world * k2 / e2, "unit": "scalar-muls/s", "ms_per_step": e2 / k2 * 1e3,
+                "window_bits": p2["c"], "num_windows": p2["num_windows"], "phases_ms_last": ph2}
+        del bases2, scalars2
+
     if rank == 0:
         total_points = n * world * args.steps
         value = total_points / elapsed
@@ -230,6 +265,8 @@ def main():
             },
             "phases_ms": mean_phase,
         }
+        if also is not None:
+            out["also"] = also
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(curve, group, min(args.cpu_sample_log2n, args.log2n))
