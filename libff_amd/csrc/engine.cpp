@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -71,7 +72,9 @@ size_t libff_log2(size_t n) {
 struct plan_t {
     int c = 0, W = 0;
     uint32_t B = 0, L = 0;
+    uint32_t S = 0, T = 0;   // entries per accumulation lane, lanes per window
     size_t off_counts = 0, off_lists = 0, off_buckets = 0, off_lvl0 = 0, off_lvl1 = 0, total = 0;
+    size_t off_pfirst = 0, off_plast = 0, off_cont = 0;
     size_t list_stride = 0;
 };
 
@@ -94,7 +97,7 @@ int choose_c(const group_vtable *vt, size_t n) {
     return best_c;
 }
 
-int make_plan(const group_vtable *vt, size_t n, int c_req, int L_req, plan_t &p) {
+int make_plan(const group_vtable *vt, size_t n, int c_req, int L_req, plan_t &p, int S_req = 0) {
     if (c_req < 0 || c_req > 24 || c_req == 1) return AMDMSM_ERR_BAD_ARG;
     p.c = c_req ? c_req : choose_c(vt, n);
     // field_get_signed_digit needs room for bits + 2 (multiexp.tcc:584-586)
@@ -106,6 +109,16 @@ int make_plan(const group_vtable *vt, size_t n, int c_req, int L_req, plan_t &p)
     p.L = L;
     const size_t xyz_bytes = (size_t)3 * vt->el_words * 4;
     p.list_stride = align_up(n ? n : 1, 64);
+    // entries per lane: enough lanes (W*T) to put >= 4 waves on every SIMD, at most 128 each
+    {
+        const double lanes_wanted = 256.0 * 4 * 4 * 64;
+        uint32_t S = 8;
+        while (S < 128 && (double)n * p.W / S > lanes_wanted) S <<= 1;
+        if (S_req > 0) S = (uint32_t)S_req;
+        p.S = S;
+        p.T = (uint32_t)((n + S - 1) / S);
+        if (p.T == 0) p.T = 1;
+    }
     size_t off = 0;
     p.off_counts = off;
     off = align_up(off + (size_t)p.W * p.B * 4, 256);
@@ -118,6 +131,12 @@ int make_plan(const group_vtable *vt, size_t n, int c_req, int L_req, plan_t &p)
     off = align_up(off + (size_t)p.W * M * xyz_bytes, 256);
     p.off_lvl1 = off;
     off = align_up(off + (size_t)p.W * ((M + p.L - 1) / p.L) * xyz_bytes, 256);
+    p.off_pfirst = off;
+    off = align_up(off + (size_t)p.W * p.T * xyz_bytes, 256);
+    p.off_plast = off;
+    off = align_up(off + (size_t)p.W * p.T * xyz_bytes, 256);
+    p.off_cont = off;
+    off = align_up(off + (size_t)p.W * p.T * 4, 256);
     p.total = off;
     return AMDMSM_OK;
 }
@@ -166,7 +185,9 @@ int msm_device_impl(amdmsm_ctx *ctx, const group_vtable *vt, const uint32_t *d_b
         return AMDMSM_OK;
     }
     plan_t p;
-    int rc = make_plan(vt, n, opts ? opts->window_bits : 0, opts ? opts->segment_len : 0, p);
+    // tuning knobs for experiments: AMDMSM_ACC_S (entries per accumulation lane)
+    static const int acc_s_env = getenv("AMDMSM_ACC_S") ? atoi(getenv("AMDMSM_ACC_S")) : 0;
+    int rc = make_plan(vt, n, opts ? opts->window_bits : 0, opts ? opts->segment_len : 0, p, acc_s_env);
     if (rc) return fail(ctx, rc, "bad window_bits / segment_len");
     rc = ensure_ws(ctx, p.total);
     if (rc) return rc;
@@ -184,7 +205,9 @@ int msm_device_impl(amdmsm_ctx *ctx, const group_vtable *vt, const uint32_t *d_b
     record(ctx, 1, st);
     vt->scatter(st, d_scalars, n, mont, p.c, p.W, counts, lists, p.list_stride);
     record(ctx, 2, st);
-    vt->accumulate(st, counts, lists, p.list_stride, d_bases, buckets, p.W, p.B);
+    HIP_TRY(ctx, hipMemsetAsync(buckets, 0, (size_t)p.W * p.B * vt->el_words * 12, st));
+    vt->accumulate(st, counts, lists, p.list_stride, d_bases, buckets, (uint32_t *)(ws + p.off_pfirst),
+                   (uint32_t *)(ws + p.off_plast), (uint32_t *)(ws + p.off_cont), p.W, p.B, p.S, p.T);
     record(ctx, 3, st);
     vt->reduce_segments(st, buckets, p.W, p.B, p.L, lvl0);
     uint32_t M = p.B / p.L;

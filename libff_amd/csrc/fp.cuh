@@ -19,6 +19,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <utility>
+
 namespace amdmsm {
 
 #define AMDMSM_DEV __device__ __forceinline__
@@ -150,28 +152,72 @@ AMDMSM_DEV void fp_cneg(Fp<P, I>& r, const Fp<P, I>& a, bool neg) {
     for (int i = 0; i < P::N; ++i) r.v[i] = neg ? n.v[i] : a.v[i];
 }
 
-// Montgomery product, CIOS, operand scanning (fp.tcc:50-228 computes the same
-// value with 64-bit limbs; R = 2^(32N) is identical).
+// 96-bit multiply-accumulate chains: acc(lo:64, hi:32) += a_i * b_i, two issues per product
+// (v_mad_u64_u32 + v_addc_co_u32, both half rate on gfx950 -- tools/ubench.hip), no
+// zero-extension moves and no separate 64-bit add.  The carry hand-off between the two needs
+// two wait states on gfx950; mac_chain.inc software-pipelines the chain over three rotating
+// carry registers so no s_nop is spent (tools/gen_mac_chains.py).
+#include "mac_chain.inc"
+
+constexpr int MAC_CHUNK = 12;   // longest generated chain
+
+// acc += sum_{i in [I0, I0+CNT)} a[i] * b[K - i]
+template <int K, int I0, size_t... J>
+AMDMSM_DEV void mac_col_vv(uint64_t& lo, uint32_t& hi, const uint32_t* a, const uint32_t* b, std::index_sequence<J...>) {
+    mac_chain<(int)sizeof...(J)>::vv(lo, hi, a[I0 + (int)J]..., b[K - I0 - (int)J]...);
+}
+template <class P, int K, int I0, size_t... J>
+AMDMSM_DEV void mac_col_vs(uint64_t& lo, uint32_t& hi, const uint32_t* m, std::index_sequence<J...>) {
+    mac_chain<(int)sizeof...(J)>::vs(lo, hi, m[I0 + (int)J]..., P::P[K - I0 - (int)J]...);
+}
+// i runs over [LO, HI): split into chunks of at most MAC_CHUNK products
+template <int K, int LO, int HI>
+AMDMSM_DEV void mac_range_vv(uint64_t& lo, uint32_t& hi, const uint32_t* a, const uint32_t* b) {
+    if constexpr (LO < HI) {
+        constexpr int CNT = (HI - LO) < MAC_CHUNK ? (HI - LO) : MAC_CHUNK;
+        mac_col_vv<K, LO>(lo, hi, a, b, std::make_index_sequence<CNT>{});
+        mac_range_vv<K, LO + CNT, HI>(lo, hi, a, b);
+    }
+}
+template <class P, int K, int LO, int HI>
+AMDMSM_DEV void mac_range_vs(uint64_t& lo, uint32_t& hi, const uint32_t* m) {
+    if constexpr (LO < HI) {
+        constexpr int CNT = (HI - LO) < MAC_CHUNK ? (HI - LO) : MAC_CHUNK;
+        mac_col_vs<P, K, LO>(lo, hi, m, std::make_index_sequence<CNT>{});
+        mac_range_vs<P, K, LO + CNT, HI>(lo, hi, m);
+    }
+}
+
+// Montgomery product a*b*R^-1 mod p, R = 2^(32N): finely integrated product scanning.
+// Column k gathers a[i]*b[k-i] and m[i]*p[k-i]; m[k] is chosen so the column's low word
+// vanishes; the upper N columns emit the result.  Same value as fp.tcc:50-228 (mul_reduce),
+// fully reduced by one conditional subtraction (2p < 2^(32N) for every supported modulus).
+template <class P, int K>
+AMDMSM_DEV void fp_mul_column(uint64_t& lo, uint32_t& hi, uint32_t* m, uint32_t* t, const uint32_t* a,
+                              const uint32_t* b) {
+    constexpr int N = P::N;
+    if constexpr (K < N) {
+        mac_range_vv<K, 0, K + 1>(lo, hi, a, b);
+        mac_range_vs<P, K, 0, K>(lo, hi, m);
+        m[K] = (uint32_t)lo * P::INV;
+        mac_chain<1>::vs(lo, hi, m[K], P::P[0]);
+    } else {
+        mac_range_vv<K, K - N + 1, N>(lo, hi, a, b);
+        mac_range_vs<P, K, K - N + 1, N>(lo, hi, m);
+        t[K - N] = (uint32_t)lo;
+    }
+    lo = (lo >> 32) | ((uint64_t)hi << 32);
+    hi = 0;
+    if constexpr (K + 1 < 2 * N) fp_mul_column<P, K + 1>(lo, hi, m, t, a, b);
+}
+
 template <class P>
 AMDMSM_DEV void fp_mul_core(uint32_t (&r)[P::N], const uint32_t (&a)[P::N], const uint32_t (&b)[P::N]) {
     constexpr int N = P::N;
-    uint32_t t[N];
-#pragma unroll
-    for (int i = 0; i < N; ++i) t[i] = 0;
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        const uint32_t bi = b[i];
-        uint64_t c = (uint64_t)a[0] * bi + t[0];
-        const uint32_t m = (uint32_t)c * P::INV;
-        uint64_t c2 = (uint64_t)m * P::P[0] + (uint32_t)c;
-#pragma unroll
-        for (int j = 1; j < N; ++j) {
-            c = (uint64_t)a[j] * bi + t[j] + (c >> 32);
-            c2 = (uint64_t)m * P::P[j] + (uint32_t)c + (c2 >> 32);
-            t[j - 1] = (uint32_t)c2;
-        }
-        t[N - 1] = (uint32_t)(c >> 32) + (uint32_t)(c2 >> 32);
-    }
+    uint32_t m[N], t[N];
+    uint64_t lo = 0;
+    uint32_t hi = 0;
+    fp_mul_column<P, 0>(lo, hi, m, t, a, b);
     fp_reduce_once<P>(t);
 #pragma unroll
     for (int i = 0; i < N; ++i) r[i] = t[i];

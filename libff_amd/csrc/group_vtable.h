@@ -32,8 +32,11 @@ struct group_vtable {
     // cursor[] holds exclusive bucket starts on entry, bucket ends on exit
     void (*scatter)(hipStream_t, const uint32_t* scalars, size_t n, int mont, int c, int W, uint32_t* cursor,
                     uint32_t* lists, size_t list_stride);
+    // segmented bucket sums: lane t of window w owns list entries [t*S, (t+1)*S); buckets[]
+    // must be zero-filled; part_first / part_last: W*T points, cont_bucket: W*T words
     void (*accumulate)(hipStream_t, const uint32_t* ends, const uint32_t* lists, size_t list_stride,
-                       const uint32_t* bases_affine, uint32_t* buckets, int W, uint32_t B);
+                       const uint32_t* bases_affine, uint32_t* buckets, uint32_t* part_first, uint32_t* part_last,
+                       uint32_t* cont_bucket, int W, uint32_t B, uint32_t S, uint32_t T);
     // out[w][s] = sum_j (s*L + j + 1) * bucket[w][s*L + j]
     void (*reduce_segments)(hipStream_t, const uint32_t* buckets, int W, uint32_t B, uint32_t L, uint32_t* out);
     // out[w][s] = sum_{j < L} in[w][s*L + j]

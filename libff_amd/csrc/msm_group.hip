@@ -9,8 +9,10 @@
 //                field_utils.tcc:167-203) -> per-(window, bucket) histogram
 //   k_scan       exclusive scan of the histogram, one workgroup per window
 //   k_scatter    second recoding pass -> per-window point lists grouped by bucket
-//   k_accumulate one lane per (window, bucket): mixed additions of its run of points
-//                (multi_exp_add_element_to_bucket_with_signed_digit, multiexp.tcc:45-81)
+//   k_accumulate one lane per S consecutive entries of a window's sorted list (segmented sum
+//                by bucket, fixed work per lane): mixed additions
+//                (multi_exp_add_element_to_bucket_with_signed_digit, multiexp.tcc:45-81);
+//                k_accumulate_fixup closes the buckets that span lanes
 //   k_reduce_segments / k_sum_level
 //                sum_b (b+1) * B_b (multiexp_accumulate_buckets, multiexp.tcc:90-125)
 //                as L-bucket running sums + a small scalar multiple per segment,
@@ -255,28 +257,104 @@ __global__ void __launch_bounds__(SCAN_TPB) k_scan(uint32_t* __restrict__ counts
 }
 
 // ------------------------------------------------------------ accumulation
+// Work-balanced bucket accumulation.  Each lane owns S CONSECUTIVE entries of one window's
+// bucket-sorted point list, whatever buckets they fall in (a segmented sum by key with
+// fixed work per lane), so a wave's lanes finish together and a bucket of any size --
+// e.g. the few, huge buckets of a short top window, or the "scalar == 1" bucket of a
+// witness vector -- is simply spread over as many lanes as it needs.
+//   * a bucket that lies entirely inside the lane's range is written straight to buckets[]
+//   * the piece of a bucket that began in an earlier lane goes to part_first[lane]
+//   * the piece of a bucket that continues into the next lane goes to part_last[lane]
+//     and its bucket index to cont_bucket[lane]
+// k_accumulate_fixup then closes every spanning bucket:
+//   bucket = part_last[t] + part_first[t+1] + ... + part_first[lane of its last entry].
+// buckets[] is zero-filled beforehand, so untouched (empty) buckets read as infinity.
+constexpr uint32_t NO_BUCKET = 0xffffffffu;
+
+// smallest b with e[b] > k   (e non-decreasing, e[B-1] > k)
+AMDMSM_DEV uint32_t bucket_of_entry(const uint32_t* __restrict__ e, uint32_t B, uint32_t k) {
+    uint32_t l = 0, r = B - 1;
+    while (l < r) {
+        const uint32_t m = (l + r) >> 1;
+        if (e[m] > k) r = m; else l = m + 1;
+    }
+    return l;
+}
+
 __global__ void __launch_bounds__(TPB) k_accumulate(const uint32_t* __restrict__ ends, const uint32_t* __restrict__ lists,
                                                     size_t list_stride, const uint32_t* __restrict__ bases,
-                                                    uint32_t* __restrict__ buckets, int W, uint32_t B) {
-    const size_t t = gtid();
-    const size_t w = t / B;
-    const uint32_t b = (uint32_t)(t % B);
+                                                    uint32_t* __restrict__ buckets, uint32_t* __restrict__ part_first,
+                                                    uint32_t* __restrict__ part_last, uint32_t* __restrict__ cont_bucket,
+                                                    int W, uint32_t B, uint32_t S, uint32_t T) {
+    const size_t g = gtid();
+    const size_t w = g / T;
+    const uint32_t t = (uint32_t)(g % T);
     if (w >= (size_t)W) return;
     const uint32_t* e = ends + w * B;
-    const uint32_t start = b ? e[b - 1] : 0u;
-    const uint32_t end = e[b];
+    const uint32_t total = e[B - 1];
+    const uint32_t lo = t * S;
+    if (lo >= total) {
+        cont_bucket[g] = NO_BUCKET;
+        return;
+    }
+    const uint32_t hi = (lo + S < total) ? lo + S : total;
+    uint32_t b = bucket_of_entry(e, B, lo);
+    uint32_t bend = e[b];
+    bool from_prev = (b ? e[b - 1] : 0u) < lo;   // first piece continues a bucket begun earlier
     const uint32_t* lst = lists + w * list_stride;
+    uint32_t* bk = buckets + w * (size_t)B * XYZW;
     Jac<EH> acc;
     jac_set_inf(acc);
-    for (uint32_t k = start; k < end; ++k) {
+    for (uint32_t k = lo; k < hi; ++k) {
+        if (k == bend) {
+            // bucket b ends here: it is complete unless its head lies in an earlier lane
+            store_jac(from_prev ? part_first + g * XYZW : bk + (size_t)b * XYZW, acc);
+            from_prev = false;
+            jac_set_inf(acc);
+            do {
+                ++b;
+                bend = e[b];
+            } while (bend == k);   // skip empty buckets (k < total = e[B-1] bounds the walk)
+        }
         const uint32_t ent = lst[k];
-        const uint32_t idx = ent & 0x7fffffffu;
         Aff<EH> p;
-        load_aff(p, bases + (size_t)idx * AFFW);
+        load_aff(p, bases + (size_t)(ent & 0x7fffffffu) * AFFW);
         el_cneg(p.y, p.y, (ent >> 31) != 0);   // -(x, y) = (x, -y); (0,0) stays infinity
         jac_madd(acc, p);
     }
-    store_jac(buckets + t * XYZW, acc);
+    if (bend == hi) {   // the last bucket ends exactly with the lane
+        store_jac(from_prev ? part_first + g * XYZW : bk + (size_t)b * XYZW, acc);
+        cont_bucket[g] = NO_BUCKET;
+    } else if (from_prev) {   // the whole lane lies inside one bucket
+        store_jac(part_first + g * XYZW, acc);
+        cont_bucket[g] = NO_BUCKET;
+    } else {   // bucket b starts in this lane and continues
+        store_jac(part_last + g * XYZW, acc);
+        cont_bucket[g] = b;
+    }
+}
+
+__global__ void __launch_bounds__(64) k_accumulate_fixup(const uint32_t* __restrict__ ends,
+                                                         const uint32_t* __restrict__ part_first,
+                                                         const uint32_t* __restrict__ part_last,
+                                                         const uint32_t* __restrict__ cont_bucket,
+                                                         uint32_t* __restrict__ buckets, int W, uint32_t B, uint32_t S,
+                                                         uint32_t T) {
+    const size_t g = gtid();
+    const size_t w = g / T;
+    const uint32_t t = (uint32_t)(g % T);
+    if (w >= (size_t)W) return;
+    const uint32_t b = cont_bucket[g];
+    if (b == NO_BUCKET) return;
+    const uint32_t bend = ends[w * B + b];
+    const uint32_t t_last = (bend - 1) / S;   // lane holding the bucket's last entry
+    Jac<E> acc, x;
+    load_jac(acc, part_last + g * XYZW);
+    for (uint32_t u = t + 1; u <= t_last; ++u) {
+        load_jac(x, part_first + (w * T + u) * XYZW);
+        jac_add(acc, acc, x);
+    }
+    store_jac(buckets + (w * B + b) * XYZW, acc);
 }
 
 // --------------------------------------------------------------- reduction
@@ -492,9 +570,12 @@ void l_scatter(hipStream_t st, const uint32_t* scalars, size_t n, int mont, int 
     hipLaunchKernelGGL(k_scatter, dim3(blocks_for(n)), dim3(TPB), 0, st, scalars, n, mont, c, W, cursor, lists, list_stride);
 }
 void l_accumulate(hipStream_t st, const uint32_t* ends, const uint32_t* lists, size_t list_stride, const uint32_t* bases,
-                  uint32_t* buckets, int W, uint32_t B) {
-    hipLaunchKernelGGL(k_accumulate, dim3(blocks_for((size_t)W * B)), dim3(TPB), 0, st, ends, lists, list_stride, bases,
-                       buckets, W, B);
+                  uint32_t* buckets, uint32_t* part_first, uint32_t* part_last, uint32_t* cont_bucket, int W, uint32_t B,
+                  uint32_t S, uint32_t T) {
+    hipLaunchKernelGGL(k_accumulate, dim3(blocks_for((size_t)W * T)), dim3(TPB), 0, st, ends, lists, list_stride, bases,
+                       buckets, part_first, part_last, cont_bucket, W, B, S, T);
+    hipLaunchKernelGGL(k_accumulate_fixup, dim3(blocks_for((size_t)W * T, 64)), dim3(64), 0, st, ends, part_first,
+                       part_last, cont_bucket, buckets, W, B, S, T);
 }
 void l_reduce_segments(hipStream_t st, const uint32_t* buckets, int W, uint32_t B, uint32_t L, uint32_t* out) {
     hipLaunchKernelGGL(k_reduce_segments, dim3(blocks_for((size_t)W * (B / L), 64)), dim3(64), 0, st, buckets, W, B, L, out);
