@@ -186,6 +186,56 @@ AMDMSM_DEV void jac_to_aff(Aff<E>& r, const Jac<E>& p) {
     el_mul(r.y, p.y, z2);
 }
 
+template <class E>
+AMDMSM_DEV void jac_shfl_xor(Jac<E>& r, const Jac<E>& p, int mask) {
+    el_shfl_xor(r.x, p.x, mask);
+    el_shfl_xor(r.y, p.y, mask);
+    el_shfl_xor(r.z, p.z, mask);
+}
+
+// Doubling (dbl-2009-l, as jac_dbl) with its seven field products spread over three lanes
+// of the wave: three rounds of products in the dependent chain instead of seven.  Every
+// lane holds the same point on entry and on exit.  Used where one point is doubled many
+// times in a row and the wave has nothing else to do (the c doublings between windows,
+// multiexp.tcc:614-616).  All 64 lanes must be active.
+template <class E>
+AMDMSM_DEV void jac_dbl_lanes3(Jac<E>& p) {
+    if (jac_is_inf(p)) return;   // wave-uniform: every lane holds the same point
+    const int lane = (int)(threadIdx.x & 63);
+    const bool l0 = lane == 0, l01 = lane <= 1;
+    E u, v, r, XX, B, YZ, C, D, F, E3, t;
+    // round 1:  lane 0: XX = X^2   lane 1: B = Y^2   lane 2: YZ = Y*Z
+    el_select(u, l0, p.x, p.y);
+    el_select(v, l01, u, p.z);
+    el_mul(r, u, v);
+    el_shfl(XX, r, 0);
+    el_shfl(B, r, 1);
+    el_shfl(YZ, r, 2);
+    el_dbl(t, XX);
+    el_add(E3, t, XX);        // E = 3*XX
+    el_add(t, p.x, B);        // X + B
+    // round 2:  lane 0: C = B^2   lane 1: (X+B)^2   lane 2: F = E^2
+    el_select(u, l0, B, t);
+    el_select(u, l01, u, E3);
+    el_mul(r, u, u);
+    el_shfl(C, r, 0);
+    el_shfl(D, r, 1);
+    el_shfl(F, r, 2);
+    el_sub(D, D, XX);
+    el_sub(D, D, C);
+    el_dbl(D, D);             // D = 2((X+B)^2 - XX - C)
+    el_dbl(t, D);
+    el_sub(p.x, F, t);        // X3 = F - 2D
+    // round 3 (same product on every lane): E*(D - X3)
+    el_sub(t, D, p.x);
+    el_mul(t, E3, t);
+    el_dbl(C, C);
+    el_dbl(C, C);
+    el_dbl(C, C);             // 8C
+    el_sub(p.y, t, C);        // Y3
+    el_dbl(p.z, YZ);          // Z3 = 2*Y*Z
+}
+
 // k * P by double-and-add (curve_utils.tcc:14-32 shape), k < 2^64
 template <class E>
 AMDMSM_DEV void jac_mul_u64(Jac<E>& r, const Jac<E>& p, unsigned long long k) {

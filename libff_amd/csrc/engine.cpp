@@ -74,7 +74,7 @@ struct plan_t {
     uint32_t B = 0, L = 0;
     uint32_t S = 0, T = 0;   // entries per accumulation lane, lanes per window
     size_t off_counts = 0, off_lists = 0, off_buckets = 0, off_lvl0 = 0, off_lvl1 = 0, total = 0;
-    size_t off_pfirst = 0, off_plast = 0, off_cont = 0;
+    size_t off_pfirst = 0, off_plast = 0, off_cont = 0, off_queue = 0;
     size_t list_stride = 0;
 };
 
@@ -103,7 +103,7 @@ int make_plan(const group_vtable *vt, size_t n, int c_req, int L_req, plan_t &p,
     // field_get_signed_digit needs room for bits + 2 (multiexp.tcc:584-586)
     p.W = (vt->fr_bits + 2 + p.c - 1) / p.c;
     p.B = (uint32_t)1 << (p.c - 1);
-    uint32_t L = L_req > 0 ? (uint32_t)L_req : 32u;
+    uint32_t L = L_req > 0 ? (uint32_t)L_req : 8u;
     while (L > p.B) L >>= 1;
     if (L == 0 || (L & (L - 1))) return AMDMSM_ERR_BAD_ARG;
     p.L = L;
@@ -137,6 +137,8 @@ int make_plan(const group_vtable *vt, size_t n, int c_req, int L_req, plan_t &p,
     off = align_up(off + (size_t)p.W * p.T * xyz_bytes, 256);
     p.off_cont = off;
     off = align_up(off + (size_t)p.W * p.T * 4, 256);
+    p.off_queue = off;
+    off = align_up(off + (2 + 2 * ((size_t)p.W * p.T / 24 + 2)) * 4, 256);
     p.total = off;
     return AMDMSM_OK;
 }
@@ -206,15 +208,18 @@ int msm_device_impl(amdmsm_ctx *ctx, const group_vtable *vt, const uint32_t *d_b
     vt->scatter(st, d_scalars, n, mont, p.c, p.W, counts, lists, p.list_stride);
     record(ctx, 2, st);
     HIP_TRY(ctx, hipMemsetAsync(buckets, 0, (size_t)p.W * p.B * vt->el_words * 12, st));
+    HIP_TRY(ctx, hipMemsetAsync(ws + p.off_queue, 0, 8, st));
     vt->accumulate(st, counts, lists, p.list_stride, d_bases, buckets, (uint32_t *)(ws + p.off_pfirst),
-                   (uint32_t *)(ws + p.off_plast), (uint32_t *)(ws + p.off_cont), p.W, p.B, p.S, p.T);
+                   (uint32_t *)(ws + p.off_plast), (uint32_t *)(ws + p.off_cont), (uint32_t *)(ws + p.off_queue), p.W,
+                   p.B, p.S, p.T);
     record(ctx, 3, st);
     vt->reduce_segments(st, buckets, p.W, p.B, p.L, lvl0);
     uint32_t M = p.B / p.L;
+    M /= std::min<uint32_t>(M, 64u);   // folded per wave inside reduce_segments
     uint32_t *src = lvl0, *dst = lvl1;
     while (M > 1) {
-        vt->sum_level(st, src, p.W, M, p.L, dst);
-        M = (M + p.L - 1) / p.L;
+        vt->sum_butterfly(st, src, p.W, M, dst);
+        M /= std::min<uint32_t>(M, 64u);
         std::swap(src, dst);
     }
     record(ctx, 4, st);

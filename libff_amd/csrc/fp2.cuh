@@ -53,7 +53,34 @@ template <class P, bool I> AMDMSM_DEV void el_set_words(Fp<P, I>& r, const uint3
     for (int i = 0; i < P::N; ++i) r.v[i] = w[i];
 }
 
+// cross-lane helpers (wave64): value of lane (lane ^ mask) / of lane src; r = pick ? a : b
+template <class P, bool I> AMDMSM_DEV void el_shfl_xor(Fp<P, I>& r, const Fp<P, I>& a, int mask) {
+#pragma unroll
+    for (int i = 0; i < P::N; ++i) r.v[i] = (uint32_t)__shfl_xor((int)a.v[i], mask, 64);
+}
+template <class P, bool I> AMDMSM_DEV void el_shfl(Fp<P, I>& r, const Fp<P, I>& a, int src) {
+#pragma unroll
+    for (int i = 0; i < P::N; ++i) r.v[i] = (uint32_t)__shfl((int)a.v[i], src, 64);
+}
+template <class P, bool I> AMDMSM_DEV void el_select(Fp<P, I>& r, bool pick, const Fp<P, I>& a, const Fp<P, I>& b) {
+#pragma unroll
+    for (int i = 0; i < P::N; ++i) r.v[i] = pick ? a.v[i] : b.v[i];
+}
+
 // ---- Fq2 overloads --------------------------------------------------------
+template <class P, int NR, bool I> AMDMSM_DEV void el_shfl_xor(Fp2<P, NR, I>& r, const Fp2<P, NR, I>& a, int mask) {
+    el_shfl_xor(r.c0, a.c0, mask);
+    el_shfl_xor(r.c1, a.c1, mask);
+}
+template <class P, int NR, bool I> AMDMSM_DEV void el_shfl(Fp2<P, NR, I>& r, const Fp2<P, NR, I>& a, int src) {
+    el_shfl(r.c0, a.c0, src);
+    el_shfl(r.c1, a.c1, src);
+}
+template <class P, int NR, bool I>
+AMDMSM_DEV void el_select(Fp2<P, NR, I>& r, bool pick, const Fp2<P, NR, I>& a, const Fp2<P, NR, I>& b) {
+    el_select(r.c0, pick, a.c0, b.c0);
+    el_select(r.c1, pick, a.c1, b.c1);
+}
 template <class P, int NR, bool I> AMDMSM_DEV void el_zero(Fp2<P, NR, I>& r) { fp_set_zero(r.c0); fp_set_zero(r.c1); }
 template <class P, int NR, bool I> AMDMSM_DEV void el_one(Fp2<P, NR, I>& r) { fp_set_one(r.c0); fp_set_zero(r.c1); }
 template <class P, int NR, bool I> AMDMSM_DEV bool el_is_zero(const Fp2<P, NR, I>& a) {

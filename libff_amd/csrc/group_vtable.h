@@ -33,14 +33,16 @@ struct group_vtable {
     void (*scatter)(hipStream_t, const uint32_t* scalars, size_t n, int mont, int c, int W, uint32_t* cursor,
                     uint32_t* lists, size_t list_stride);
     // segmented bucket sums: lane t of window w owns list entries [t*S, (t+1)*S); buckets[]
-    // must be zero-filled; part_first / part_last: W*T points, cont_bucket: W*T words
+    // must be zero-filled; part_first / part_last: W*T points, cont_bucket: W*T words;
+    // long_queue: 2 + 2*(W*T/24 + 1) words, word 0 zeroed (queue of buckets spanning many lanes)
     void (*accumulate)(hipStream_t, const uint32_t* ends, const uint32_t* lists, size_t list_stride,
                        const uint32_t* bases_affine, uint32_t* buckets, uint32_t* part_first, uint32_t* part_last,
-                       uint32_t* cont_bucket, int W, uint32_t B, uint32_t S, uint32_t T);
-    // out[w][s] = sum_j (s*L + j + 1) * bucket[w][s*L + j]
+                       uint32_t* cont_bucket, uint32_t* long_queue, int W, uint32_t B, uint32_t S, uint32_t T);
+    // M = B/L segments per window, G = min(M, 64):
+    // out[w][g] = sum over segments s in [g*G, (g+1)*G) of sum_j (s*L + j + 1) * bucket[w][s*L + j]
     void (*reduce_segments)(hipStream_t, const uint32_t* buckets, int W, uint32_t B, uint32_t L, uint32_t* out);
-    // out[w][s] = sum_{j < L} in[w][s*L + j]
-    void (*sum_level)(hipStream_t, const uint32_t* in, int W, uint32_t M, uint32_t L, uint32_t* out);
+    // out[w][g] = sum_{i in [g*G, (g+1)*G)} in[w][i], G = min(M, 64)
+    void (*sum_butterfly)(hipStream_t, const uint32_t* in, int W, uint32_t M, uint32_t* out);
     // Horner over window sums (high to low, c doublings between), write one point
     void (*horner)(hipStream_t, const uint32_t* window_sums, int W, int c, int form, uint32_t* out);
     // sum of k engine-Jacobian points

@@ -13,10 +13,10 @@
 //                by bucket, fixed work per lane): mixed additions
 //                (multi_exp_add_element_to_bucket_with_signed_digit, multiexp.tcc:45-81);
 //                k_accumulate_fixup closes the buckets that span lanes
-//   k_reduce_segments / k_sum_level
+//   k_reduce_segments / k_sum_butterfly
 //                sum_b (b+1) * B_b (multiexp_accumulate_buckets, multiexp.tcc:90-125)
-//                as L-bucket running sums + a small scalar multiple per segment,
-//                then an L-ary tree of plain sums
+//                as L-bucket running sums + a small scalar multiple per segment, folded
+//                64:1 per wave with XOR butterflies
 //   k_horner     high-to-low window combination with c doublings (multiexp.tcc:612-629)
 //
 // All windows are processed at once: the libff loop "for round ... signed_digits_round"
@@ -167,18 +167,54 @@ AMDMSM_DEV void load_scalar(uint32_t (&s)[FRW], const uint32_t* scalars, size_t 
     for (int j = 0; j < FRW; ++j) s[j] = x.v[j];
 }
 
+// Histogram / cursor updates with wave-level aggregation of hot keys.  With uniformly random
+// digits the 64 lanes of a wave hit 64 different counters and every lane issues its own
+// atomic (the loop below exits after one cheap probe).  Skewed inputs -- the short top
+// window whose few buckets receive every point, witness vectors full of 0/1 scalars -- put
+// most lanes on one counter; then the lanes that share the first active lane's key are
+// served by ONE atomic (count) or one atomic plus a lane rank (scatter), round after round,
+// until the leading key is rare again.  Must be called by every lane of the wave.
+constexpr int HOT_KEY_MIN = 8;
+
+template <bool WANT_POS>
+AMDMSM_DEV uint32_t wave_key_add(uint32_t* __restrict__ ctr, uint32_t key, bool active) {
+    uint32_t pos = 0;
+    const uint32_t lane = threadIdx.x & 63u;
+    for (;;) {
+        const unsigned long long m = __ballot(active);
+        if (!m) break;
+        const int leader = __ffsll((long long)m) - 1;
+        const uint32_t k0 = (uint32_t)__shfl((int)key, leader, 64);
+        const unsigned long long same = __ballot(active && key == k0);
+        const int cnt = __popcll(same);
+        if (cnt < HOT_KEY_MIN) break;
+        uint32_t base = 0;
+        if ((int)lane == leader) base = atomicAdd(&ctr[k0], (uint32_t)cnt);
+        if (WANT_POS) {
+            base = (uint32_t)__shfl((int)base, leader, 64);
+            if (active && key == k0) pos = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+        }
+        active = active && key != k0;
+    }
+    if (active) pos = atomicAdd(&ctr[key], 1u);
+    return pos;
+}
+
 __global__ void __launch_bounds__(TPB) k_count(const uint32_t* __restrict__ scalars, size_t n, int mont, int c, int W,
                                                uint32_t* __restrict__ counts) {
     const size_t i = gtid();
-    if (i >= n) return;
+    const bool live = i < n;
     uint32_t s[FRW];
-    load_scalar(s, scalars, i, mont);
+    if (live) {
+        load_scalar(s, scalars, i, mont);
+    } else {
+#pragma unroll
+        for (int j = 0; j < FRW; ++j) s[j] = 0;   // recodes to all-zero digits
+    }
     const size_t B = (size_t)1 << (c - 1);
     for_each_signed_digit(s, c, W, [&](int w, int32_t d) {
-        if (d != 0) {
-            const uint32_t idx = (uint32_t)(d < 0 ? -d : d) - 1u;
-            atomicAdd(&counts[(size_t)w * B + idx], 1u);
-        }
+        const uint32_t idx = (uint32_t)(d < 0 ? -d : d) - 1u;
+        wave_key_add<false>(counts + (size_t)w * B, idx, d != 0);
     });
 }
 
@@ -186,17 +222,20 @@ __global__ void __launch_bounds__(TPB) k_scatter(const uint32_t* __restrict__ sc
                                                  uint32_t* __restrict__ cursor, uint32_t* __restrict__ lists,
                                                  size_t list_stride) {
     const size_t i = gtid();
-    if (i >= n) return;
+    const bool live = i < n;
     uint32_t s[FRW];
-    load_scalar(s, scalars, i, mont);
+    if (live) {
+        load_scalar(s, scalars, i, mont);
+    } else {
+#pragma unroll
+        for (int j = 0; j < FRW; ++j) s[j] = 0;
+    }
     const size_t B = (size_t)1 << (c - 1);
     for_each_signed_digit(s, c, W, [&](int w, int32_t d) {
-        if (d != 0) {
-            const uint32_t neg = d < 0 ? 1u : 0u;
-            const uint32_t idx = (uint32_t)(neg ? -d : d) - 1u;
-            const uint32_t pos = atomicAdd(&cursor[(size_t)w * B + idx], 1u);
-            lists[(size_t)w * list_stride + pos] = (uint32_t)i | (neg << 31);
-        }
+        const uint32_t neg = d < 0 ? 1u : 0u;
+        const uint32_t idx = (uint32_t)(neg ? -d : d) - 1u;
+        const uint32_t pos = wave_key_add<true>(cursor + (size_t)w * B, idx, d != 0);
+        if (d != 0) lists[(size_t)w * list_stride + pos] = (uint32_t)i | (neg << 31);
     });
 }
 
@@ -334,12 +373,18 @@ __global__ void __launch_bounds__(TPB) k_accumulate(const uint32_t* __restrict__
     }
 }
 
+AMDMSM_DEV void wave_group_sum(Jac<E>& p, uint32_t G);
+
+// Spans of up to LONG_SPAN lanes are closed by the lane's own thread; longer ones (a bucket
+// holding a large share of a window) are queued and closed by a whole wave each.
+constexpr uint32_t LONG_SPAN = 24;
+
 __global__ void __launch_bounds__(64) k_accumulate_fixup(const uint32_t* __restrict__ ends,
                                                          const uint32_t* __restrict__ part_first,
                                                          const uint32_t* __restrict__ part_last,
                                                          const uint32_t* __restrict__ cont_bucket,
-                                                         uint32_t* __restrict__ buckets, int W, uint32_t B, uint32_t S,
-                                                         uint32_t T) {
+                                                         uint32_t* __restrict__ buckets, uint32_t* __restrict__ long_queue,
+                                                         int W, uint32_t B, uint32_t S, uint32_t T) {
     const size_t g = gtid();
     const size_t w = g / T;
     const uint32_t t = (uint32_t)(g % T);
@@ -348,6 +393,12 @@ __global__ void __launch_bounds__(64) k_accumulate_fixup(const uint32_t* __restr
     if (b == NO_BUCKET) return;
     const uint32_t bend = ends[w * B + b];
     const uint32_t t_last = (bend - 1) / S;   // lane holding the bucket's last entry
+    if (t_last - t > LONG_SPAN) {
+        const uint32_t slot = atomicAdd(&long_queue[0], 1u);
+        long_queue[2 + 2 * (size_t)slot] = (uint32_t)g;
+        long_queue[3 + 2 * (size_t)slot] = (uint32_t)(g >> 32);
+        return;
+    }
     Jac<E> acc, x;
     load_jac(acc, part_last + g * XYZW);
     for (uint32_t u = t + 1; u <= t_last; ++u) {
@@ -357,56 +408,102 @@ __global__ void __launch_bounds__(64) k_accumulate_fixup(const uint32_t* __restr
     store_jac(buckets + (w * B + b) * XYZW, acc);
 }
 
+// one wave per queued bucket: lanes stride over its partials, XOR butterfly, lane 0 stores
+__global__ void __launch_bounds__(64) k_accumulate_fixup_long(const uint32_t* __restrict__ ends,
+                                                              const uint32_t* __restrict__ part_first,
+                                                              const uint32_t* __restrict__ part_last,
+                                                              const uint32_t* __restrict__ cont_bucket,
+                                                              uint32_t* __restrict__ buckets,
+                                                              const uint32_t* __restrict__ long_queue, uint32_t B,
+                                                              uint32_t S, uint32_t T) {
+    const uint32_t count = long_queue[0];
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t q = blockIdx.x; q < count; q += gridDim.x) {
+        const size_t g = (size_t)long_queue[2 + 2 * (size_t)q] | ((size_t)long_queue[3 + 2 * (size_t)q] << 32);
+        const size_t w = g / T;
+        const uint32_t t = (uint32_t)(g % T);
+        const uint32_t b = cont_bucket[g];
+        const uint32_t t_last = (ends[w * B + b] - 1) / S;
+        Jac<E> acc, x;
+        if (lane == 0) load_jac(acc, part_last + g * XYZW); else jac_set_inf(acc);
+        for (uint32_t u = t + 1 + lane; u <= t_last; u += 64) {
+            load_jac(x, part_first + (w * T + u) * XYZW);
+            jac_add(acc, acc, x);
+        }
+        wave_group_sum(acc, 64);
+        if (lane == 0) store_jac(buckets + (w * B + b) * XYZW, acc);
+    }
+}
+
 // --------------------------------------------------------------- reduction
-__global__ void __launch_bounds__(TPB) k_reduce_segments(const uint32_t* __restrict__ buckets, int W, uint32_t B,
-                                                         uint32_t L, uint32_t* __restrict__ out) {
+// Wave-level plain sum: lanes whose index differs only in the low log2(G) bits are summed
+// into the lane with those bits clear (XOR butterfly over ds_bpermute).  Every lane of the
+// wave must call it; lanes outside the data carry infinity.
+AMDMSM_DEV void wave_group_sum(Jac<E>& p, uint32_t G) {
+    Jac<E> other;
+    for (uint32_t off = 1; off < G; off <<= 1) {
+        jac_shfl_xor(other, p, (int)off);
+        jac_add(p, p, other);
+    }
+}
+
+// sum_b (b + 1) * B_b for one window, first level: each lane takes L consecutive buckets
+// with the running-sum recurrence of multiexp_accumulate_buckets (multiexp.tcc:109-122),
+// adds (s*L) * (plain sum) for the weight offset of its segment, and the wave then folds
+// G = min(M, 64) neighbouring segments.  out[w][s / G].
+__global__ void __launch_bounds__(64) k_reduce_segments(const uint32_t* __restrict__ buckets, int W, uint32_t B,
+                                                        uint32_t L, uint32_t* __restrict__ out) {
     const size_t t = gtid();
     const uint32_t M = B / L;
+    const uint32_t G = M < 64u ? M : 64u;
     const size_t w = t / M;
     const uint32_t s = (uint32_t)(t % M);
-    if (w >= (size_t)W) return;
-    const uint32_t* seg = buckets + (w * B + (size_t)s * L) * XYZW;
+    const bool valid = w < (size_t)W;
     Jac<E> acc, sum, bk;
     jac_set_inf(acc);
     jac_set_inf(sum);
-    for (uint32_t j = L; j-- > 0;) {
-        load_jac(bk, seg + (size_t)j * XYZW);
-        jac_add(acc, acc, bk);    // acc = sum_{k >= j} B_k
-        jac_add(sum, sum, acc);   // sum = sum_k (k - j + 1) B_k
+    if (valid) {
+        const uint32_t* seg = buckets + (w * B + (size_t)s * L) * XYZW;
+        for (uint32_t j = L; j-- > 0;) {
+            load_jac(bk, seg + (size_t)j * XYZW);
+            jac_add(acc, acc, bk);    // acc = sum_{k >= j} B_k
+            jac_add(sum, sum, acc);   // sum = sum_k (k - j + 1) B_k
+        }
+        // segment's buckets carry weights s*L + j + 1: add (s*L) * acc
+        jac_mul_u64(bk, acc, (unsigned long long)s * L);
+        jac_add(sum, sum, bk);
     }
-    // segment's buckets carry weights s*L + j + 1: add (s*L) * acc
-    jac_mul_u64(bk, acc, (unsigned long long)s * L);
-    jac_add(sum, sum, bk);
-    store_jac(out + t * XYZW, sum);
+    wave_group_sum(sum, G);
+    if (valid && (s % G) == 0) store_jac(out + (w * (M / G) + s / G) * XYZW, sum);
 }
 
-__global__ void __launch_bounds__(TPB) k_sum_level(const uint32_t* __restrict__ in, int W, uint32_t M, uint32_t L,
-                                                   uint32_t* __restrict__ out) {
+// plain sums: out[w][i / G] = sum of in[w][i .. i + G), G = min(M, 64)
+__global__ void __launch_bounds__(64) k_sum_butterfly(const uint32_t* __restrict__ in, int W, uint32_t M,
+                                                      uint32_t* __restrict__ out) {
     const size_t t = gtid();
-    const uint32_t Mo = (M + L - 1) / L;
-    const size_t w = t / Mo;
-    const uint32_t s = (uint32_t)(t % Mo);
-    if (w >= (size_t)W) return;
-    Jac<E> acc, x;
-    jac_set_inf(acc);
-    const uint32_t lo = s * L, hi = (lo + L < M) ? lo + L : M;
-    for (uint32_t j = lo; j < hi; ++j) {
-        load_jac(x, in + (w * M + j) * XYZW);
-        jac_add(acc, acc, x);
-    }
-    store_jac(out + t * XYZW, acc);
+    const uint32_t G = M < 64u ? M : 64u;
+    const size_t w = t / M;
+    const uint32_t i = (uint32_t)(t % M);
+    const bool valid = w < (size_t)W;
+    Jac<E> p;
+    if (valid) load_jac(p, in + t * XYZW); else jac_set_inf(p);
+    wave_group_sum(p, G);
+    if (valid && (i % G) == 0) store_jac(out + (w * (M / G) + i / G) * XYZW, p);
 }
 
-__global__ void k_horner(const uint32_t* __restrict__ window_sums, int W, int c, int form, uint32_t* __restrict__ out) {
-    if (gtid() != 0) return;
+// Horner over the window sums, high to low, c doublings between windows
+// (multiexp.tcc:612-629).  One wave; every lane carries the same running point so the
+// doublings can borrow lanes 0..2 for their field products (jac_dbl_lanes3).
+__global__ void __launch_bounds__(64) k_horner(const uint32_t* __restrict__ window_sums, int W, int c, int form,
+                                               uint32_t* __restrict__ out) {
     Jac<E> res, x;
     load_jac(res, window_sums + (size_t)(W - 1) * XYZW);
     for (int w = W - 2; w >= 0; --w) {
-        for (int i = 0; i < c; ++i) jac_dbl(res, res);
+        for (int i = 0; i < c; ++i) jac_dbl_lanes3(res);
         load_jac(x, window_sums + (size_t)w * XYZW);
         jac_add(res, res, x);
     }
-    store_out(out, res, form);
+    if (threadIdx.x == 0) store_out(out, res, form);
 }
 
 __global__ void k_sum_points(const uint32_t* __restrict__ pts, int k, int form, uint32_t* __restrict__ out) {
@@ -570,19 +667,21 @@ void l_scatter(hipStream_t st, const uint32_t* scalars, size_t n, int mont, int 
     hipLaunchKernelGGL(k_scatter, dim3(blocks_for(n)), dim3(TPB), 0, st, scalars, n, mont, c, W, cursor, lists, list_stride);
 }
 void l_accumulate(hipStream_t st, const uint32_t* ends, const uint32_t* lists, size_t list_stride, const uint32_t* bases,
-                  uint32_t* buckets, uint32_t* part_first, uint32_t* part_last, uint32_t* cont_bucket, int W, uint32_t B,
-                  uint32_t S, uint32_t T) {
+                  uint32_t* buckets, uint32_t* part_first, uint32_t* part_last, uint32_t* cont_bucket,
+                  uint32_t* long_queue, int W, uint32_t B, uint32_t S, uint32_t T) {
     hipLaunchKernelGGL(k_accumulate, dim3(blocks_for((size_t)W * T)), dim3(TPB), 0, st, ends, lists, list_stride, bases,
                        buckets, part_first, part_last, cont_bucket, W, B, S, T);
     hipLaunchKernelGGL(k_accumulate_fixup, dim3(blocks_for((size_t)W * T, 64)), dim3(64), 0, st, ends, part_first,
-                       part_last, cont_bucket, buckets, W, B, S, T);
+                       part_last, cont_bucket, buckets, long_queue, W, B, S, T);
+    const size_t max_long = (size_t)W * T / LONG_SPAN + 1;
+    hipLaunchKernelGGL(k_accumulate_fixup_long, dim3((unsigned)(max_long < 2048 ? max_long : 2048)), dim3(64), 0, st, ends,
+                       part_first, part_last, cont_bucket, buckets, long_queue, B, S, T);
 }
 void l_reduce_segments(hipStream_t st, const uint32_t* buckets, int W, uint32_t B, uint32_t L, uint32_t* out) {
     hipLaunchKernelGGL(k_reduce_segments, dim3(blocks_for((size_t)W * (B / L), 64)), dim3(64), 0, st, buckets, W, B, L, out);
 }
-void l_sum_level(hipStream_t st, const uint32_t* in, int W, uint32_t M, uint32_t L, uint32_t* out) {
-    const uint32_t Mo = (M + L - 1) / L;
-    hipLaunchKernelGGL(k_sum_level, dim3(blocks_for((size_t)W * Mo, 64)), dim3(64), 0, st, in, W, M, L, out);
+void l_sum_butterfly(hipStream_t st, const uint32_t* in, int W, uint32_t M, uint32_t* out) {
+    hipLaunchKernelGGL(k_sum_butterfly, dim3(blocks_for((size_t)W * M, 64)), dim3(64), 0, st, in, W, M, out);
 }
 void l_horner(hipStream_t st, const uint32_t* window_sums, int W, int c, int form, uint32_t* out) {
     hipLaunchKernelGGL(k_horner, dim3(1), dim3(64), 0, st, window_sums, W, c, form, out);
@@ -633,7 +732,7 @@ void l_madd_bench(hipStream_t st, const uint32_t* pts, uint32_t* out, size_t nth
 
 const group_vtable g_vt = {
     GP::CURVE, GP::GROUP, FRW, EW, FR::BITS, GP::LIBFF_PROJECTIVE ? 1 : 0, FR::R,
-    l_import_bases, l_count, l_scatter, l_accumulate, l_reduce_segments, l_sum_level, l_horner, l_sum_points,
+    l_import_bases, l_count, l_scatter, l_accumulate, l_reduce_segments, l_sum_butterfly, l_horner, l_sum_points,
     l_gen_bases_seq, l_export_affine, l_field_op, l_group_op, l_digits, l_mul_bench, l_madd_bench,
 };
 

@@ -231,3 +231,30 @@ def test_full_size_closed_form_and_sharding(engine, port, name, curve, group, lo
     assert (got == want).all()
     got = engine.multi_exp(curve, group, bases, sc, base_form=multi_exp_base_form_special, chunks=8)
     assert (got == want).all()
+
+
+@pytest.mark.parametrize("name,curve,group", [GROUPS[0], GROUPS[2], GROUPS[3]])
+def test_skewed_scalars(engine, port, name, curve, group):
+    """Witness-like scalar vectors (multiexp.tcc:690-757 exists because of them): mostly 0 / 1 /
+    a few repeated values, so single buckets receive a large share of a window and the
+    wave-aggregated histogram and the long-span bucket fix-up paths run."""
+    n = 30000 if group == 1 else 6000
+    rng = np.random.default_rng(7)
+    sc = port.scalars_sha512(curve, 555, n)
+    special = small_scalars_mont(port, curve, [0, 1, 2, 3])
+    pick = rng.integers(0, 8, size=n)
+    for v in range(4):
+        sc[pick == v] = special[v]
+    sc[pick == 4] = sc[0]          # one random value repeated ~n/8 times
+    bases = port.bases_seq(curve, group, n, first=3)
+    want = port.multi_exp(curve, group, bases, sc, port.BDLO12_SIGNED, 1, chunks=8, omp=True)
+    for c in (0, 7, 14):
+        got = engine.multi_exp(curve, group, bases, sc, base_form=multi_exp_base_form_special, window_bits=c)
+        assert (got == want).all(), c
+    got, stats = engine.multi_exp_filter_one_zero(curve, group, bases, sc, base_form=multi_exp_base_form_special)
+    assert (got == want).all()
+    assert stats["skipped"] == int((pick == 0).sum()) and stats["ones"] == int((pick == 1).sum())
+    # every scalar identical: one bucket per window holds all n points
+    same = np.repeat(sc[5:6], n, axis=0)
+    want = port.multi_exp(curve, group, bases, same, port.BDLO12_SIGNED, 1, chunks=8, omp=True)
+    assert (engine.multi_exp(curve, group, bases, same, base_form=multi_exp_base_form_special) == want).all()
