@@ -1,0 +1,46 @@
+/* FFI-convention entry points for multi-scalar multiplication on MI355X.
+ *
+ * These extend the reference's C ABI (clearmatics/libff ffi/ffi.h:19-95) in its own
+ * style: `bool` return, (const void *, size_t) buffer pairs, never throws.  The reference
+ * FFI has *_init, *_g1_add, *_g1_mul and *_pairing for bls12_377 and bw6_761 but no
+ * multi-exponentiation; a host that today loops over `<curve>_g1_mul` + `<curve>_g1_add`
+ * (ffi.cpp:36-54, 16-34) calls one of these instead.
+ *
+ * Wire format (ffi/ffi_serialization.hpp:12-16, ffi_serialization.tcc:19-187), unchanged:
+ *   field element  big-endian, plain (non-Montgomery), left-padded to the in-memory
+ *                  bigint size: alt_bn128 Fr 32 B / Fq 32 B; bls12_377 Fr 32 B / Fq 48 B;
+ *                  bw6_761 Fr 48 B / Fq 96 B
+ *   G1 element     affine X || Y (alt_bn128 64 B, bls12_377 96 B, bw6_761 192 B); zero = (0, 1)
+ *   bases_g1       n consecutive G1 elements, scalars_fr n consecutive Fr elements
+ * Validation on read is the reference's (group_element_read, ffi_serialization.tcc:150-171):
+ * exact sizes, every integer < its modulus, is_well_formed(), is_in_safe_subgroup().  On any
+ * failure the function returns false and leaves `out_g1` untouched.
+ *
+ * The symbols bls12_377_init / bw6_761_init etc. of ffi.h are NOT redefined here, so this
+ * library can be loaded next to libff-ffi.  No init call is needed for the functions below;
+ * amdmsm_ffi_set_device() optionally selects the GPU (default 0) before the first call.
+ */
+#ifndef LIBFF_AMD_FFI_H
+#define LIBFF_AMD_FFI_H
+#include <stdbool.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+bool amdmsm_ffi_set_device(int device);
+
+bool alt_bn128_g1_multiexp(const void *bases_g1, size_t bases_g1_size, const void *scalars_fr,
+                           size_t scalars_fr_size, void *out_g1, size_t out_g1_size);
+
+bool bls12_377_g1_multiexp(const void *bases_g1, size_t bases_g1_size, const void *scalars_fr,
+                           size_t scalars_fr_size, void *out_g1, size_t out_g1_size);
+
+bool bw6_761_g1_multiexp(const void *bases_g1, size_t bases_g1_size, const void *scalars_fr,
+                         size_t scalars_fr_size, void *out_g1, size_t out_g1_size);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIBFF_AMD_FFI_H */

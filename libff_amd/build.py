@@ -27,7 +27,8 @@ ARCH = "gfx950"
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-I" + INCLUDE, "-I" + CSRC,
           "-Wno-unused-result"]
 DEVICE_DEPS = ["msm_group.hip", "fp.cuh", "fp2.cuh", "ec.cuh", "curve_params.h", "group_vtable.h", os.path.join(HERE, "build.py")]
-HOST_DEPS = ["engine.cpp", "group_vtable.h", os.path.join(INCLUDE, "amdmsm.h")]
+HOST_DEPS = ["engine.cpp", "ffi.cpp", "engine_internal.h", "group_vtable.h", os.path.join(INCLUDE, "amdmsm.h"),
+             os.path.join(INCLUDE, "libff_amd_ffi.h")]
 
 
 def hipcc():
@@ -65,10 +66,11 @@ def build(force=False, verbose=True, jobs=None):
         if force or _newer(o, DEVICE_DEPS):
             tasks.append([cc, *COMMON, "-c", os.path.join(CSRC, "msm_group.hip"),
                           f"-DAMDMSM_GROUP={g}", f"-DAMDMSM_VT=vt_{g}", *GROUP_FLAGS.get(g, []), "-o", o])
-    eo = os.path.join(OBJ, "engine.o")
-    objs.append(eo)
-    if force or _newer(eo, HOST_DEPS):
-        tasks.append([cc, *COMMON, "-x", "hip", "-c", os.path.join(CSRC, "engine.cpp"), "-o", eo])
+    for src in ("engine", "ffi"):
+        eo = os.path.join(OBJ, f"{src}.o")
+        objs.append(eo)
+        if force or _newer(eo, HOST_DEPS):
+            tasks.append([cc, *COMMON, "-x", "hip", "-c", os.path.join(CSRC, f"{src}.cpp"), "-o", eo])
     if tasks:
         if verbose:
             print(f"[libff_amd.build] compiling {len(tasks)} translation unit(s) for {ARCH} ...", flush=True)

@@ -236,6 +236,25 @@ AMDMSM_DEV void jac_dbl_lanes3(Jac<E>& p) {
     el_dbl(p.z, YZ);          // Z3 = 2*Y*Z
 }
 
+// k * P for a compile-time scalar given as NW little-endian 32-bit words (curve_utils.tcc:14-32)
+template <class E, int NW>
+AMDMSM_DEV void jac_mul_words(Jac<E>& r, const Jac<E>& p, const uint32_t (&k)[NW]) {
+    Jac<E> acc;
+    jac_set_inf(acc);
+    bool found_one = false;
+    for (int i = NW * 32 - 1; i >= 0; --i) {
+        uint32_t w = 0;
+#pragma unroll
+        for (int j = 0; j < NW; ++j) w = ((i >> 5) == j) ? k[j] : w;
+        if (found_one) jac_dbl(acc, acc);
+        if ((w >> (i & 31)) & 1u) {
+            found_one = true;
+            jac_add(acc, acc, p);
+        }
+    }
+    r = acc;
+}
+
 // k * P by double-and-add (curve_utils.tcc:14-32 shape), k < 2^64
 template <class E>
 AMDMSM_DEV void jac_mul_u64(Jac<E>& r, const Jac<E>& p, unsigned long long k) {

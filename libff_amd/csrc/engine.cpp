@@ -2,6 +2,7 @@
 // pipeline schedule and the host-buffer entry points.  All arithmetic happens in
 // the kernels of msm_group.hip; there is no CPU arithmetic path in this library.
 #include "../../include/amdmsm.h"
+#include "engine_internal.h"
 #include "group_vtable.h"
 
 #include <hip/hip_runtime.h>
@@ -231,6 +232,9 @@ int msm_device_impl(amdmsm_ctx *ctx, const group_vtable *vt, const uint32_t *d_b
 }
 
 }  // namespace
+
+const group_vtable *amdmsm_internal_find_vt(int curve, int group) { return find_vt(curve, group); }
+void *amdmsm_internal_stream(amdmsm_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
 extern "C" {
 

@@ -65,6 +65,18 @@ AMDMSM_DEV bool fp_eq(const Fp<P, I>& a, const Fp<P, I>& b) {
     return acc == 0;
 }
 
+// a < p as plain integers
+template <class P, bool I>
+AMDMSM_DEV bool fp_lt_modulus(const Fp<P, I>& a) {
+    uint32_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < P::N; ++i) {
+        const uint64_t s = (uint64_t)a.v[i] - P::P[i] - borrow;
+        borrow = (uint32_t)(s >> 63);
+    }
+    return borrow != 0;
+}
+
 // r = a - p if a >= p (a < 2p), branch-free select.
 template <class P>
 AMDMSM_DEV void fp_reduce_once(uint32_t (&t)[P::N]) {

@@ -67,7 +67,18 @@ template <class P, bool I> AMDMSM_DEV void el_select(Fp<P, I>& r, bool pick, con
     for (int i = 0; i < P::N; ++i) r.v[i] = pick ? a.v[i] : b.v[i];
 }
 
+template <class P, bool I> AMDMSM_DEV void el_to_mont(Fp<P, I>& r, const Fp<P, I>& a) { fp_to_mont(r, a); }
+template <class P, bool I> AMDMSM_DEV void el_from_mont(Fp<P, I>& r, const Fp<P, I>& a) { fp_from_mont(r, a); }
+
 // ---- Fq2 overloads --------------------------------------------------------
+template <class P, int NR, bool I> AMDMSM_DEV void el_to_mont(Fp2<P, NR, I>& r, const Fp2<P, NR, I>& a) {
+    fp_to_mont(r.c0, a.c0);
+    fp_to_mont(r.c1, a.c1);
+}
+template <class P, int NR, bool I> AMDMSM_DEV void el_from_mont(Fp2<P, NR, I>& r, const Fp2<P, NR, I>& a) {
+    fp_from_mont(r.c0, a.c0);
+    fp_from_mont(r.c1, a.c1);
+}
 template <class P, int NR, bool I> AMDMSM_DEV void el_shfl_xor(Fp2<P, NR, I>& r, const Fp2<P, NR, I>& a, int mask) {
     el_shfl_xor(r.c0, a.c0, mask);
     el_shfl_xor(r.c1, a.c1, mask);

@@ -52,6 +52,12 @@ struct group_vtable {
     // compact affine -> libff special-form records (x, y, 1) / (0, 1, 0)
     void (*export_affine)(hipStream_t, const uint32_t* src_affine, size_t n, uint32_t* dst_xyz);
 
+    // libff FFI wire format (big-endian plain affine, ffi_serialization.tcc) <-> engine layout;
+    // *status receives OR of: 1 out of range, 2 not on curve, 4 not in the safe subgroup
+    void (*ffi_decode_points)(hipStream_t, const uint32_t* src_be, size_t n, uint32_t* dst_affine, uint32_t* status);
+    void (*ffi_decode_scalars)(hipStream_t, const uint32_t* src_be, size_t n, uint32_t* dst_plain, uint32_t* status);
+    void (*ffi_encode_point)(hipStream_t, const uint32_t* src_xyz_affine, uint32_t* dst_be);
+
     // ---- test hooks (parity of the primitives against the oracle) ----------
     // coordinate-field op over arrays: 0 mul 1 sqr 2 add 3 sub 4 neg 5 inverse
     void (*field_op)(hipStream_t, int op, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t n);

@@ -570,6 +570,127 @@ __global__ void __launch_bounds__(TPB) k_gen_bases_seq(unsigned long long first,
     store_aff(dst + i * AFFW, a);
 }
 
+// -------------------------------------------------------------- FFI codecs
+// libff's FFI wire format (ffi/ffi_serialization.hpp:12-16, .tcc:19-187): every prime-field
+// component is a big-endian plain (non-Montgomery) integer padded to the in-memory bigint
+// size, extension coefficients highest-order first, points are affine X || Y, zero = (0, 1).
+AMDMSM_DEV uint32_t bswap32(uint32_t v) { return __builtin_bswap32(v); }
+
+// one Fq component: BE bytes -> LE words; false when the value is not < modulus (:65-76)
+template <bool I>
+AMDMSM_DEV bool load_be_plain(Fp<FQ, I>& r, const uint32_t* __restrict__ src) {
+#pragma unroll
+    for (int j = 0; j < FQ::N; ++j) r.v[j] = bswap32(src[FQ::N - 1 - j]);
+    return fp_lt_modulus(r);
+}
+template <bool I>
+AMDMSM_DEV void store_be_plain(uint32_t* __restrict__ dst, const Fp<FQ, I>& a) {
+#pragma unroll
+    for (int j = 0; j < FQ::N; ++j) dst[FQ::N - 1 - j] = bswap32(a.v[j]);
+}
+AMDMSM_DEV bool load_coord_be(Fp<FQ, false>& r, const uint32_t* src) { return load_be_plain(r, src); }
+AMDMSM_DEV void store_coord_be(uint32_t* dst, const Fp<FQ, false>& a) { store_be_plain(dst, a); }
+template <int NR>
+AMDMSM_DEV bool load_coord_be(Fp2<FQ, NR, false>& r, const uint32_t* src) {
+    const bool ok1 = load_be_plain(r.c1, src);   // field_serializer: coeffs[degree-1] first (:25-36)
+    const bool ok0 = load_be_plain(r.c0, src + FQ::N);
+    return ok0 && ok1;
+}
+template <int NR>
+AMDMSM_DEV void store_coord_be(uint32_t* dst, const Fp2<FQ, NR, false>& a) {
+    store_be_plain(dst, a.c1);
+    store_be_plain(dst + FQ::N, a.c0);
+}
+
+// bls12_377 G1: P + [c1] sigma(P) == 0, sigma(x, y) = (beta x, y) (bls12_377_g1.cpp:359-365, 387-397)
+template <class G, int K = G::SUBGROUP_CHECK>
+struct endo_check {
+    static AMDMSM_DEV bool run(const Aff<E>&) { return true; }
+};
+template <class G>
+struct endo_check<G, 2> {
+    static AMDMSM_DEV bool run(const Aff<E>& a) {
+        Jac<E> p, sg, t;
+        jac_from_aff(p, a);
+        E beta;
+        el_set_words(beta, G::ENDO_BETA);
+        sg = p;
+        el_mul(sg.x, sg.x, beta);
+        jac_mul_words<E, 4>(t, sg, G::ENDO_C1);
+        jac_add(t, t, p);
+        return jac_is_inf(t);
+    }
+};
+template <class G>
+AMDMSM_DEV bool endo_subgroup_check(const Aff<E>& a) { return endo_check<G>::run(a); }
+
+AMDMSM_DEV bool in_safe_subgroup(const Aff<E>& a) {
+    if (GP::SUBGROUP_CHECK == 0) return true;   // alt_bn128_g1.cpp:359-363
+    Jac<E> p, t;
+    jac_from_aff(p, a);
+    if (GP::SUBGROUP_CHECK == 1) {               // zero() == scalar_field::mod * P (bw6_761_g1.cpp:385-388)
+        jac_mul_words<E, FRW>(t, p, FR::P);
+        return jac_is_inf(t);
+    }
+    return endo_subgroup_check<GP>(a);
+}
+
+// status bits: 1 = coordinate out of range, 2 = not on the curve, 4 = not in the safe subgroup
+__global__ void __launch_bounds__(TPB) k_ffi_decode_points(const uint32_t* __restrict__ src, size_t n,
+                                                           uint32_t* __restrict__ dst, uint32_t* __restrict__ status) {
+    const size_t i = gtid();
+    if (i >= n) return;
+    const uint32_t* q = src + i * AFFW;
+    Aff<E> a;
+    const bool okx = load_coord_be(a.x, q);
+    const bool oky = load_coord_be(a.y, q + EW);
+    uint32_t bad = (okx && oky) ? 0u : 1u;
+    E one_plain;
+    el_zero(one_plain);
+    reinterpret_cast<uint32_t*>(&one_plain)[0] = 1u;
+    if (el_is_zero(a.x) && el_eq(a.y, one_plain)) {
+        el_zero(a.x);   // (0, 1) encodes zero (group_element_read, :158-163)
+        el_zero(a.y);
+    } else if (!bad) {
+        el_to_mont(a.x, a.x);
+        el_to_mont(a.y, a.y);
+        // is_well_formed: y^2 = x^3 + b (e.g. bls12_377_g1.cpp:367-385 with Z = 1)
+        E y2, x3, b;
+        el_sqr(y2, a.y);
+        el_sqr(x3, a.x);
+        el_mul(x3, x3, a.x);
+        el_set_words(b, GP::COEFF_B);
+        el_add(x3, x3, b);
+        if (!el_eq(y2, x3)) bad |= 2u;
+        else if (!in_safe_subgroup(a)) bad |= 4u;
+    }
+    if (bad) atomicOr(status, bad);
+    store_aff(dst + i * AFFW, a);
+}
+
+__global__ void __launch_bounds__(TPB) k_ffi_decode_scalars(const uint32_t* __restrict__ src, size_t n,
+                                                            uint32_t* __restrict__ dst, uint32_t* __restrict__ status) {
+    const size_t i = gtid();
+    if (i >= n) return;
+    Fp<FR> s;
+#pragma unroll
+    for (int j = 0; j < FRW; ++j) s.v[j] = bswap32(src[i * FRW + FRW - 1 - j]);
+    if (!fp_lt_modulus(s)) atomicOr(status, 1u);
+    fp_store(dst + i * FRW, s);   // plain bigint: run the MSM with scalars_plain
+}
+
+// (x, y, 1) / (0, 1, 0) Montgomery record -> wire format (group_element_write, :173-187)
+__global__ void k_ffi_encode_point(const uint32_t* __restrict__ src_xyz, uint32_t* __restrict__ dst) {
+    if (gtid() != 0) return;
+    E x, y;
+    el_load(x, src_xyz);
+    el_load(y, src_xyz + EW);
+    el_from_mont(x, x);
+    el_from_mont(y, y);
+    store_coord_be(dst, x);
+    store_coord_be(dst + EW, y);
+}
+
 // -------------------------------------------------------------- test hooks
 __global__ void __launch_bounds__(TPB) k_field_op(int op, const uint32_t* __restrict__ a, const uint32_t* __restrict__ b,
                                                   uint32_t* __restrict__ out, size_t n) {
@@ -697,6 +818,17 @@ void l_export_affine(hipStream_t st, const uint32_t* src, size_t n, uint32_t* ds
     if (!n) return;
     hipLaunchKernelGGL(k_export_affine, dim3(blocks_for(n)), dim3(TPB), 0, st, src, n, dst);
 }
+void l_ffi_decode_points(hipStream_t st, const uint32_t* src, size_t n, uint32_t* dst, uint32_t* status) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_ffi_decode_points, dim3(blocks_for(n)), dim3(TPB), 0, st, src, n, dst, status);
+}
+void l_ffi_decode_scalars(hipStream_t st, const uint32_t* src, size_t n, uint32_t* dst, uint32_t* status) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_ffi_decode_scalars, dim3(blocks_for(n)), dim3(TPB), 0, st, src, n, dst, status);
+}
+void l_ffi_encode_point(hipStream_t st, const uint32_t* src_xyz, uint32_t* dst) {
+    hipLaunchKernelGGL(k_ffi_encode_point, dim3(1), dim3(64), 0, st, src_xyz, dst);
+}
 void l_field_op(hipStream_t st, int op, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t n) {
     if (!n) return;
     hipLaunchKernelGGL(k_field_op, dim3(blocks_for(n)), dim3(TPB), 0, st, op, a, b, out, n);
@@ -733,7 +865,7 @@ void l_madd_bench(hipStream_t st, const uint32_t* pts, uint32_t* out, size_t nth
 const group_vtable g_vt = {
     GP::CURVE, GP::GROUP, FRW, EW, FR::BITS, GP::LIBFF_PROJECTIVE ? 1 : 0, FR::R,
     l_import_bases, l_count, l_scatter, l_accumulate, l_reduce_segments, l_sum_butterfly, l_horner, l_sum_points,
-    l_gen_bases_seq, l_export_affine, l_field_op, l_group_op, l_digits, l_mul_bench, l_madd_bench,
+    l_gen_bases_seq, l_export_affine, l_ffi_decode_points, l_ffi_decode_scalars, l_ffi_encode_point, l_field_op, l_group_op, l_digits, l_mul_bench, l_madd_bench,
 };
 
 }  // namespace

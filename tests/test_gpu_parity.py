@@ -258,3 +258,69 @@ def test_skewed_scalars(engine, port, name, curve, group):
     same = np.repeat(sc[5:6], n, axis=0)
     want = port.multi_exp(curve, group, bases, same, port.BDLO12_SIGNED, 1, chunks=8, omp=True)
     assert (engine.multi_exp(curve, group, bases, same, base_form=multi_exp_base_form_special) == want).all()
+
+
+def _be_bytes(limbs_le):
+    """uint64 LE limb array -> big-endian byte string (object_write_to_buffer, ffi_serialization.tcc:117-136)."""
+    return np.frombuffer(np.ascontiguousarray(limbs_le, dtype=np.uint64).tobytes()[::-1], dtype=np.uint8)
+
+
+@pytest.mark.parametrize("name,curve,sym", [("alt_bn128_g1", 0, "alt_bn128_g1_multiexp"),
+                                             ("bls12_377_g1", 1, "bls12_377_g1_multiexp"),
+                                             ("bw6_761_g1", 2, "bw6_761_g1_multiexp")])
+def test_ffi_multiexp(engine, port, name, curve, sym):
+    """The FFI-convention symbols (include/libff_amd_ffi.h): big-endian plain affine in and out,
+    reference validation rules (ffi_serialization.tcc:150-171), false + untouched output on error.
+    Expected bytes come from the oracle's restatement of group_element_write."""
+    import ctypes
+
+    lib = engine.lib
+    fn = getattr(lib, sym)
+    fn.restype = ctypes.c_bool
+    n = 300 if curve != 2 else 120
+    bases = port.bases_seq(curve, 1, n, first=17)
+    sc = port.scalars_sha512(curve, 900, n)
+    s = port.sizes(curve, 1)
+    cb, fb = s["coord_bytes"], s["fr_bytes"]
+    bases_buf = np.concatenate([port.ffi_group_write(curve, 1, b) for b in bases])
+    sc_buf = np.concatenate([port.ffi_fr_write(curve, x) for x in sc])
+    want = port.ffi_group_write(curve, 1, port.multi_exp(curve, 1, bases, sc, port.BDLO12_SIGNED, 1))
+    out = np.zeros(2 * cb, dtype=np.uint8)
+
+    def call(b, sv, o):
+        return bool(fn(b.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(b.size),
+                       sv.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(sv.size),
+                       o.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(o.size)))
+
+    assert call(bases_buf, sc_buf, out)
+    assert (out == want).all()
+    # a zero base ((0, 1) encoding) is accepted and ignored
+    zero_enc = port.ffi_group_write(curve, 1, port.group_consts(curve, 1)[1])
+    b2 = bases_buf.copy()
+    b2[: 2 * cb] = zero_enc
+    bz = bases.copy()
+    bz[0] = port.group_consts(curve, 1)[1]
+    want2 = port.ffi_group_write(curve, 1, port.multi_exp(curve, 1, bz, sc, port.BDLO12_SIGNED, 1))
+    assert call(b2, sc_buf, out) and (out == want2).all()
+    # failures: wrong sizes, coordinate >= modulus, point off the curve, scalar >= r
+    sentinel = np.full(2 * cb, 0xA5, dtype=np.uint8)
+    for bad_b, bad_s, o in (
+        (bases_buf[:-1], sc_buf, sentinel.copy()),
+        (bases_buf, sc_buf[:-fb], sentinel.copy()),
+        (bases_buf, sc_buf, np.full(2 * cb - 1, 0xA5, dtype=np.uint8)),
+    ):
+        assert not call(np.ascontiguousarray(bad_b), np.ascontiguousarray(bad_s), o)
+        assert (o == 0xA5).all()
+    for mutate in ("range", "curve", "scalar"):
+        b3, s3, o = bases_buf.copy(), sc_buf.copy(), sentinel.copy()
+        if mutate == "range":
+            b3[5 * 2 * cb: 5 * 2 * cb + cb] = 0xFF
+        elif mutate == "curve":
+            b3[7 * 2 * cb + 2 * cb - 1] ^= 1
+        else:
+            s3[3 * fb: 4 * fb] = 0xFF
+        assert not call(b3, s3, o), mutate
+        assert (o == 0xA5).all(), mutate
+    # empty input -> zero = (0, 1)
+    assert call(np.zeros(0, dtype=np.uint8), np.zeros(0, dtype=np.uint8), out)
+    assert (out == zero_enc).all()

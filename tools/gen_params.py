@@ -23,7 +23,7 @@ CURVES = {
         r=0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001,
         q=0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47,
         coords="jacobian",
-        g1=dict(deg=1, x=[1], y=[2], b=[3]),
+        g1=dict(deg=1, x=[1], y=[2], b=[3], subgroup="none"),   # alt_bn128_g1.cpp:359-363
         g2=dict(
             deg=2,
             nr=-1,
@@ -45,6 +45,11 @@ CURVES = {
             x=[0x8848DEFE740A67C8FC6225BF87FF5485951E2CAA9D41BB188282C8BD37CB5CD5481512FFCD394EEAB9B16EB21BE9EF],
             y=[0x1914A69C5102EFF1F674F5D30AFEEC4BD7FB348CA3E52D96D182AD44FB82305C2FE3D3634A9591AFD82DE55559C8EA6],
             b=[1],
+            # is_in_safe_subgroup, bls12_377_g1.cpp:387-397: P + [c1] sigma(P) == 0,
+            # sigma(x, y) = (beta * x, y)  (bls12_377_init.cpp:344-349)
+            subgroup="endo",
+            beta=80949648264912719408558363140637477264845294720710499478137287262712535938301461879813459410945,
+            c1=0x452217CC900000010A11800000000001,
         ),
         g2=dict(
             deg=2,
@@ -67,6 +72,7 @@ CURVES = {
             x=[0x1075B020EA190C8B277CE98A477BEAEE6A0CFB7551B27F0EE05C54B85F56FC779017FFAC15520AC11DBFCD294C2E746A17A54CE47729B905BD71FA0C9EA097103758F9A280CA27F6750DD0356133E82055928ACA6AF603F4088F3AF66E5B43D],
             y=[0x58B84E0A6FC574E6FD637B45CC2A420F952589884C9EC61A7348D2A2E573A3265909F1AF7E0DBAC5B8FA1771B5B806CC685D31717A4C55BE3FB90B6FC2CDD49F9DF141B3053253B2B08119CAD0FB93AD1CB2BE0B20D2A1BAFC8F2DB4E95363],
             b=[-1],
+            subgroup="order",   # bw6_761_g1.cpp:385-388: [r]P == 0
         ),
         g2=dict(
             deg=1,
@@ -162,6 +168,13 @@ def emit_device_header():
             w(f"    static constexpr bool LIBFF_PROJECTIVE = {'true' if c['coords'] == 'projective' else 'false'};"
               "  // libff in-memory coords are homogeneous projective")
             w(f"    static constexpr int NR_SMALL = {g.get('nr', 0)};     // Fq2 = Fq[u]/(u^2 - NR); 0 when DEG == 1")
+            sub = g.get("subgroup", "order")
+            w(f"    static constexpr int SUBGROUP_CHECK = {dict(none=0, order=1, endo=2)[sub]};   "
+              "// 0 none, 1 [r]P == 0, 2 P + [c1]sigma(P) == 0")
+            if sub == "endo":
+                w(f"    static constexpr uint32_t ENDO_BETA[{n}] = "
+                  f"{c_arr(limbs(g['beta'] * fq['R'] % c['q'], n, 32), '0x%08xu')};")
+                w(f"    static constexpr uint32_t ENDO_C1[4] = {c_arr(limbs(g['c1'], 4, 32), '0x%08xu')};")
             if deg == 2:
                 nr = g["nr"] % c["q"]
                 w(f"    static constexpr uint32_t NR_MONT[{n}] = "
