@@ -78,7 +78,7 @@ def build(force=False, verbose=True, jobs=None):
         with concurrent.futures.ThreadPoolExecutor(max_workers=jobs) as ex:
             list(ex.map(_run, tasks))
     if tasks or not os.path.exists(SO_PATH):
-        _run([cc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", SO_PATH, *objs])
+        _run([cc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-Wl,-soname,libamdmsm.so", "-o", SO_PATH, *objs])
         if verbose:
             print(f"[libff_amd.build] linked {SO_PATH}", flush=True)
     return SO_PATH

@@ -53,3 +53,20 @@ done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
 g++ -shared -fopenmp -o "$OUT/libff_ref.so" "${objs[@]}" $GMPLIB -lcrypto -lpthread
 echo "built $OUT/libff_ref.so"
+
+# End-to-end check of the drop-in template shim with real libff types: the reference's own
+# multi_exp<> call sites compiled against include/libff_amd/multiexp.hpp + libamdmsm.so.
+AMDSO="$HERE/../libff_amd/libamdmsm.so"
+if [ -f "$AMDSO" ]; then
+    refobjs=()
+    for o in "${objs[@]}"; do
+        case "$o" in *ref_shim.o) ;; *) refobjs+=("$o") ;; esac
+    done
+    g++ "${FLAGS[@]}" -I"$HERE/../include" -c "$HERE/shim_check.cpp" -o "$OBJ/shim_check.o"
+    g++ -fopenmp -o "$OUT/shim_check" "$OBJ/shim_check.o" "${refobjs[@]}" -L"$HERE/../libff_amd" -lamdmsm \
+        -Wl,-rpath,'$ORIGIN/../../libff_amd' -Wl,-rpath,/opt/rocm/lib -Wl,--allow-shlib-undefined \
+        $GMPLIB -lcrypto -lpthread
+    echo "built $OUT/shim_check"
+else
+    echo "libamdmsm.so not built yet; skipping shim_check" >&2
+fi

@@ -1,0 +1,76 @@
+// TEST INFRASTRUCTURE ONLY -- end-to-end check of the drop-in template shim
+// (include/libff_amd/multiexp.hpp) against the *unmodified* reference library.
+//
+// Built by oracle/build_ref.sh into oracle/_ref/shim_check (git-ignored; links the
+// reference objects compiled in place from /root/reference and libamdmsm.so).  The program
+// uses nothing but libff's public API: with the shim included, libff::multi_exp<...,
+// BDLO12[_signed], ...> runs on the GPU while multi_exp_method_naive_plain stays libff's own
+// CPU code, so comparing the two with libff's operator== is the reference's own test idea
+// (test_multiexp.cpp:205-256) applied across the boundary.  Run on the GPU box by
+// tests/test_gpu_shim.py.
+#include <libff/algebra/curves/alt_bn128/alt_bn128_pp.hpp>
+#include <libff/algebra/curves/bls12_377/bls12_377_pp.hpp>
+#include <libff/algebra/curves/bw6_761/bw6_761_pp.hpp>
+#include <libff/common/profiling.hpp>
+#include <libff/common/rng.hpp>
+
+#include <libff_amd/multiexp.hpp>
+
+#include <cstdio>
+#include <vector>
+
+using namespace libff;
+
+static int failures = 0;
+
+template<typename G, typename Fr> void check_group(const char *name, const std::vector<size_t> &sizes)
+{
+    for (const size_t n : sizes) {
+        std::vector<G> bases;
+        std::vector<Fr> scalars;
+        G cur = G::one();
+        for (size_t i = 0; i < n; ++i) {
+            bases.push_back(cur);
+            cur = cur + G::one();
+            scalars.push_back(SHA512_rng<Fr>(1000 + i));
+        }
+        std::vector<G> special = bases;
+        batch_to_special<G>(special);
+        if (n > 3) {
+            scalars[1] = Fr::zero();
+            scalars[2] = Fr::one();
+        }
+        const G expect = multi_exp<G, Fr, multi_exp_method_naive_plain>(
+            bases.cbegin(), bases.cend(), scalars.cbegin(), scalars.cend(), 1);
+        const G r1 = multi_exp<G, Fr, multi_exp_method_BDLO12_signed, multi_exp_base_form_special>(
+            special.cbegin(), special.cend(), scalars.cbegin(), scalars.cend(), 1);
+        const G r2 = multi_exp<G, Fr, multi_exp_method_BDLO12_signed, multi_exp_base_form_normal>(
+            bases.cbegin(), bases.cend(), scalars.cbegin(), scalars.cend(), 3);
+        const G r3 = multi_exp<G, Fr, multi_exp_method_BDLO12>(
+            bases.cbegin(), bases.cend(), scalars.cbegin(), scalars.cend(), 2);
+        const G r4 = multi_exp_filter_one_zero<G, Fr, multi_exp_method_BDLO12_signed, multi_exp_base_form_special>(
+            special.cbegin(), special.cend(), scalars.cbegin(), scalars.cend(), 1);
+        const bool ok = (expect == r1) && (expect == r2) && (expect == r3) && (expect == r4);
+        printf("%-14s n=%-6zu %s\n", name, n, ok ? "ok" : "MISMATCH");
+        if (!ok) {
+            ++failures;
+        }
+    }
+}
+
+int main()
+{
+    inhibit_profiling_info = true;
+    inhibit_profiling_counters = true;
+    alt_bn128_pp::init_public_params();
+    bls12_377_pp::init_public_params();
+    bw6_761_pp::init_public_params();
+    check_group<alt_bn128_G1, alt_bn128_Fr>("alt_bn128_G1", {1, 2, 5, 257, 4096});
+    check_group<alt_bn128_G2, alt_bn128_Fr>("alt_bn128_G2", {1, 5, 600});
+    check_group<bls12_377_G1, bls12_377_Fr>("bls12_377_G1", {1, 5, 1500});
+    check_group<bls12_377_G2, bls12_377_Fr>("bls12_377_G2", {1, 5, 300});
+    check_group<bw6_761_G1, bw6_761_Fr>("bw6_761_G1", {1, 5, 300});
+    check_group<bw6_761_G2, bw6_761_Fr>("bw6_761_G2", {1, 5, 300});
+    printf(failures ? "SHIM CHECK FAILED (%d)\n" : "SHIM CHECK PASSED\n", failures);
+    return failures ? 1 : 0;
+}
