@@ -76,20 +76,27 @@ struct plan_t {
     uint32_t S = 0, T = 0;   // entries per accumulation lane, lanes per window
     size_t off_counts = 0, off_lists = 0, off_buckets = 0, off_lvl0 = 0, off_lvl1 = 0, total = 0;
     size_t off_pfirst = 0, off_plast = 0, off_cont = 0, off_queue = 0;
+    size_t off_coarse = 0, off_cursor = 0, off_tmp_payload = 0, off_tmp_key = 0;
     size_t list_stride = 0;
 };
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-// Window size: minimise  W(c) * (n * madd + 2^(c-1) * 2 * add)  in field multiplications.
+// Window size.  Measured on MI355X (alt_bn128 G1; the ratios carry over to the other fields):
+// sort + accumulation cost ~0.137 ns per (point, window) entry and the bucket reduction
+// ~0.8 ns per bucket.  A top window that keeps only 2..8 significant bits concentrates all of
+// its n entries in a handful of buckets, which the second sort level (one workgroup per coarse
+// bin) processes almost serially -- such c are penalised rather than forbidden.
 int choose_c(const group_vtable *vt, size_t n) {
     if (n == 0) return 2;
     double best = 1e300;
     int best_c = 2;
     for (int c = 2; c <= 22; ++c) {
-        const double W = (double)((vt->fr_bits + 2 + c - 1) / c);
+        const int W = (vt->fr_bits + 2 + c - 1) / c;
         const double B = (double)((size_t)1 << (c - 1));
-        const double cost = W * ((double)n * 11.0 + B * (2.0 * 17.0 + 2.0));
+        double cost = (double)W * ((double)n * 0.137 + B * 0.8);
+        const int top_bits = vt->fr_bits + 1 - (W - 1) * c;   // bit positions left for the top window
+        if (top_bits >= 2 && top_bits <= 8) cost += (double)n * 3.0 / (double)(1 << (top_bits - 1));
         if (cost < best) {
             best = cost;
             best_c = c;
@@ -140,6 +147,15 @@ int make_plan(const group_vtable *vt, size_t n, int c_req, int L_req, plan_t &p,
     off = align_up(off + (size_t)p.W * p.T * 4, 256);
     p.off_queue = off;
     off = align_up(off + (2 + 2 * ((size_t)p.W * p.T / 24 + 2)) * 4, 256);
+    // two-level sort scratch
+    p.off_coarse = off;
+    off = align_up(off + (size_t)p.W * 1025 * 4, 256);
+    p.off_cursor = off;
+    off = align_up(off + (size_t)p.W * 1024 * 4, 256);
+    p.off_tmp_payload = off;
+    off = align_up(off + (size_t)p.W * p.list_stride * 4, 256);
+    p.off_tmp_key = off;
+    off = align_up(off + (size_t)p.W * p.list_stride * 4, 256);
     p.total = off;
     return AMDMSM_OK;
 }
@@ -203,10 +219,19 @@ int msm_device_impl(amdmsm_ctx *ctx, const group_vtable *vt, const uint32_t *d_b
 
     ctx->ev_stream = st;
     record(ctx, 0, st);
-    HIP_TRY(ctx, hipMemsetAsync(counts, 0, (size_t)p.W * p.B * 4, st));
-    vt->count(st, d_scalars, n, mont, p.c, p.W, counts);
-    record(ctx, 1, st);
-    vt->scatter(st, d_scalars, n, mont, p.c, p.W, counts, lists, p.list_stride);
+    static const bool atomic_sort = getenv("AMDMSM_SORT") && !strcmp(getenv("AMDMSM_SORT"), "atomic");
+    if (atomic_sort || p.c > 22) {
+        HIP_TRY(ctx, hipMemsetAsync(counts, 0, (size_t)p.W * p.B * 4, st));
+        vt->count(st, d_scalars, n, mont, p.c, p.W, counts);
+        record(ctx, 1, st);
+        vt->scatter(st, d_scalars, n, mont, p.c, p.W, counts, lists, p.list_stride);
+    } else {
+        HIP_TRY(ctx, hipMemsetAsync(ws + p.off_coarse, 0, (size_t)p.W * 1025 * 4, st));
+        record(ctx, 1, st);
+        vt->sort(st, d_scalars, n, mont, p.c, p.W, (uint32_t *)(ws + p.off_coarse), (uint32_t *)(ws + p.off_cursor),
+                 (int32_t *)lists, (uint32_t *)(ws + p.off_tmp_payload), (uint32_t *)(ws + p.off_tmp_key), counts, lists,
+                 p.list_stride);
+    }
     record(ctx, 2, st);
     HIP_TRY(ctx, hipMemsetAsync(buckets, 0, (size_t)p.W * p.B * vt->el_words * 12, st));
     HIP_TRY(ctx, hipMemsetAsync(ws + p.off_queue, 0, 8, st));

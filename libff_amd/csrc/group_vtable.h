@@ -32,6 +32,12 @@ struct group_vtable {
     // cursor[] holds exclusive bucket starts on entry, bucket ends on exit
     void (*scatter)(hipStream_t, const uint32_t* scalars, size_t n, int mont, int c, int W, uint32_t* cursor,
                     uint32_t* lists, size_t list_stride);
+    // LDS-staged two-level sort (same result as count + scatter): ends[w][b] and lists[w][...].
+    // coarse: W*(2^hb+1) words zeroed, cursor: W*2^hb words, digits/tmp_payload/tmp_key/lists:
+    // W*stride words each (digits may alias lists); hb = min(10, c-1); needs c <= 23
+    void (*sort)(hipStream_t, const uint32_t* scalars, size_t n, int mont, int c, int W, uint32_t* coarse,
+                 uint32_t* cursor, int32_t* digits, uint32_t* tmp_payload, uint32_t* tmp_key, uint32_t* ends,
+                 uint32_t* lists, size_t stride);
     // segmented bucket sums: lane t of window w owns list entries [t*S, (t+1)*S); buckets[]
     // must be zero-filled; part_first / part_last: W*T points, cont_bucket: W*T words;
     // long_queue: 2 + 2*(W*T/24 + 1) words, word 0 zeroed (queue of buckets spanning many lanes)

@@ -295,6 +295,220 @@ __global__ void __launch_bounds__(SCAN_TPB) k_scan(uint32_t* __restrict__ counts
     }
 }
 
+// ------------------------------------------------- LDS-staged two-level sort
+// Grouping the n*W (point, window) entries by bucket with one global atomic and one scattered
+// 4-byte store per entry (k_count / k_scatter above) runs at the L2 atomic rate (~25 G/s) and
+// is half of a 2^26-point MSM.  This path keeps the atomics in LDS and makes every global write
+// a run of neighbouring entries:
+//   k_sort_digits   one pass over the scalars: signed digits to digits[w][i] (coalesced) and a
+//                   histogram over the top HB bits of the bucket index ("coarse bin"), per
+//                   workgroup in LDS, merged with one global atomic per (workgroup, bin)
+//   k_sort_scan     exclusive scan of the coarse histogram (2^HB + 1 entries per window)
+//   k_sort_coarse   workgroup (tile, w): LDS counting sort of a tile's nonzero digits by coarse
+//                   bin, one global atomic per (tile, bin) to reserve space, runs written to
+//                   tmp[w] as (payload, bucket) pairs
+//   k_sort_fine     workgroup (bin, w): LDS histogram of the bin by the low FB bits -> ends[],
+//                   then chunk-wise LDS counting sort -> lists[w] (runs per fine bucket)
+// bucket index = |digit| - 1 = (coarse << FB) | fine, HB = min(10, c-1), FB = c-1-HB.
+constexpr int SORT_TPB = 1024;
+constexpr int SORT_TILE = 8192;     // entries per k_sort_coarse workgroup
+constexpr int SORT_CHUNK = 16384;   // entries per k_sort_fine chunk
+constexpr int SORT_MAX_HB = 10;
+constexpr int SORT_MAX_FB = 11;     // c <= 22
+
+AMDMSM_DEV uint32_t digit_payload(size_t i, int32_t d) { return (uint32_t)i | (d < 0 ? 0x80000000u : 0u); }
+
+// exclusive scan of cnt[0..len) (LDS) into out[0..len) by one workgroup of SORT_TPB threads;
+// len <= 8 * SORT_TPB.  tmp: SORT_TPB/64 + 1 words of LDS.  Returns the total in every thread.
+AMDMSM_DEV uint32_t block_exclusive_scan(const uint32_t* cnt, uint32_t* out, uint32_t len, uint32_t* tmp) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t per = (len + SORT_TPB - 1) / SORT_TPB;   // <= 8
+    const uint32_t i0 = tid * per;
+    uint32_t v[8];
+    uint32_t tsum = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 8; ++k) {
+        v[k] = (k < per && i0 + k < len) ? cnt[i0 + k] : 0u;
+        tsum += v[k];
+    }
+    uint32_t inc = tsum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)inc, off, 64);
+        if ((int)lane >= off) inc += o;
+    }
+    __syncthreads();   // protect tmp / out reuse
+    if (lane == 63) tmp[wave] = inc;
+    __syncthreads();
+    uint32_t wave_off = 0, total = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < SORT_TPB / 64; ++k) {
+        const uint32_t ws = tmp[k];
+        if (k < wave) wave_off += ws;
+        total += ws;
+    }
+    uint32_t excl = wave_off + inc - tsum;
+#pragma unroll
+    for (uint32_t k = 0; k < 8; ++k) {
+        if (k < per && i0 + k < len) out[i0 + k] = excl;
+        excl += v[k];
+    }
+    __syncthreads();
+    return total;
+}
+
+__global__ void __launch_bounds__(SORT_TPB) k_sort_digits(const uint32_t* __restrict__ scalars, size_t n, int mont, int c,
+                                                          int W, int hb, uint32_t per_block, int32_t* __restrict__ digits,
+                                                          size_t stride, uint32_t* __restrict__ coarse_counts) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];   // [W][2^hb]
+    const uint32_t nbin = 1u << hb;
+    const int fb = c - 1 - hb;
+    for (uint32_t j = threadIdx.x; j < (uint32_t)W * nbin; j += SORT_TPB) smem[j] = 0;
+    __syncthreads();
+    const size_t base = (size_t)blockIdx.x * per_block;
+    for (uint32_t k = threadIdx.x; k < per_block; k += SORT_TPB) {
+        const size_t i = base + k;
+        if (i >= n) break;
+        uint32_t s[FRW];
+        load_scalar(s, scalars, i, mont);
+        for_each_signed_digit(s, c, W, [&](int w, int32_t d) {
+            digits[(size_t)w * stride + i] = d;
+            if (d != 0) {
+                const uint32_t idx = (uint32_t)(d < 0 ? -d : d) - 1u;
+                atomicAdd(&smem[(uint32_t)w * nbin + (idx >> fb)], 1u);
+            }
+        });
+    }
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < (uint32_t)W * nbin; j += SORT_TPB) {
+        const uint32_t v = smem[j];
+        if (v) atomicAdd(&coarse_counts[(j / nbin) * (nbin + 1) + (j % nbin)], v);
+    }
+}
+
+// counts[w][0..nbin] -> exclusive starts (entry nbin = window total); cursor = copy of the starts
+__global__ void __launch_bounds__(SORT_TPB) k_sort_scan(uint32_t* __restrict__ coarse, uint32_t* __restrict__ cursor,
+                                                        uint32_t nbin) {
+    __shared__ uint32_t cnt[1 << SORT_MAX_HB], out[1 << SORT_MAX_HB], tmp[SORT_TPB / 64 + 1];
+    uint32_t* g = coarse + (size_t)blockIdx.x * (nbin + 1);
+    for (uint32_t j = threadIdx.x; j < nbin; j += SORT_TPB) cnt[j] = g[j];
+    __syncthreads();
+    const uint32_t total = block_exclusive_scan(cnt, out, nbin, tmp);
+    for (uint32_t j = threadIdx.x; j < nbin; j += SORT_TPB) {
+        g[j] = out[j];
+        cursor[(size_t)blockIdx.x * nbin + j] = out[j];
+    }
+    if (threadIdx.x == 0) g[nbin] = total;
+}
+
+__global__ void __launch_bounds__(SORT_TPB) k_sort_coarse(const int32_t* __restrict__ digits, size_t n, size_t stride, int c,
+                                                          int hb, uint32_t* __restrict__ cursor,
+                                                          uint32_t* __restrict__ tmp_payload,
+                                                          uint32_t* __restrict__ tmp_key) {
+    __shared__ uint32_t hist[1 << SORT_MAX_HB], lstart[1 << SORT_MAX_HB], lcur[1 << SORT_MAX_HB],
+        gbase[1 << SORT_MAX_HB], tmp[SORT_TPB / 64 + 1];
+    __shared__ uint32_t st_payload[SORT_TILE], st_key[SORT_TILE];
+    const uint32_t nbin = 1u << hb;
+    const int fb = c - 1 - hb;
+    const uint32_t w = blockIdx.y;
+    const size_t tile0 = (size_t)blockIdx.x * SORT_TILE;
+    for (uint32_t j = threadIdx.x; j < nbin; j += SORT_TPB) hist[j] = 0;
+    __syncthreads();
+    constexpr int PER = SORT_TILE / SORT_TPB;
+    uint32_t idx[PER], pay[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const size_t i = tile0 + (size_t)k * SORT_TPB + threadIdx.x;
+        const int32_t d = (i < n) ? digits[(size_t)w * stride + i] : 0;
+        idx[k] = d ? (uint32_t)(d < 0 ? -d : d) - 1u : 0xffffffffu;
+        pay[k] = digit_payload(i, d);
+        if (d) atomicAdd(&hist[idx[k] >> fb], 1u);
+    }
+    __syncthreads();
+    const uint32_t total = block_exclusive_scan(hist, lstart, nbin, tmp);
+    for (uint32_t j = threadIdx.x; j < nbin; j += SORT_TPB) {
+        const uint32_t h = hist[j];
+        lcur[j] = lstart[j];
+        gbase[j] = h ? atomicAdd(&cursor[(size_t)w * nbin + j], h) : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        if (idx[k] != 0xffffffffu) {
+            const uint32_t r = atomicAdd(&lcur[idx[k] >> fb], 1u);
+            st_payload[r] = pay[k];
+            st_key[r] = idx[k];
+        }
+    }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < total; k += SORT_TPB) {
+        const uint32_t key = st_key[k];
+        const uint32_t bin = key >> fb;
+        const size_t pos = (size_t)w * stride + gbase[bin] + (k - lstart[bin]);
+        tmp_payload[pos] = st_payload[k];
+        tmp_key[pos] = key;
+    }
+}
+
+__global__ void __launch_bounds__(SORT_TPB) k_sort_fine(const uint32_t* __restrict__ tmp_payload,
+                                                        const uint32_t* __restrict__ tmp_key,
+                                                        const uint32_t* __restrict__ coarse, size_t stride, int c, int hb,
+                                                        uint32_t chunk_cap, uint32_t* __restrict__ ends,
+                                                        uint32_t* __restrict__ lists) {
+    // dynamic LDS: 4 arrays of nfine words, chunk_cap payload words, chunk_cap fine keys (u16)
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    __shared__ uint32_t tmp[SORT_TPB / 64 + 1];
+    const uint32_t nbin = 1u << hb;
+    const int fb = c - 1 - hb;
+    const uint32_t nfine = 1u << fb, fmask = nfine - 1u;
+    uint32_t* fstart = smem;
+    uint32_t* chist = fstart + nfine;
+    uint32_t* cstart = chist + nfine;
+    uint32_t* ccur = cstart + nfine;
+    uint32_t* st_payload = ccur + nfine;
+    unsigned short* st_fine = reinterpret_cast<unsigned short*>(st_payload + chunk_cap);
+    const uint32_t bin = blockIdx.x, w = blockIdx.y;
+    const uint32_t* cs = coarse + (size_t)w * (nbin + 1);
+    const uint32_t b0 = cs[bin], m = cs[bin + 1] - b0;
+    const uint32_t* key = tmp_key + (size_t)w * stride + b0;
+    const uint32_t* pay = tmp_payload + (size_t)w * stride + b0;
+    uint32_t* out = lists + (size_t)w * stride + b0;
+    uint32_t* e = ends + (((size_t)w << (c - 1)) + ((size_t)bin << fb));
+    // pass A: sizes of the fine buckets of this bin -> ends[]
+    for (uint32_t j = threadIdx.x; j < nfine; j += SORT_TPB) chist[j] = 0;
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < m; k += SORT_TPB) atomicAdd(&chist[key[k] & fmask], 1u);
+    __syncthreads();
+    block_exclusive_scan(chist, fstart, nfine, tmp);
+    for (uint32_t j = threadIdx.x; j < nfine; j += SORT_TPB) e[j] = b0 + fstart[j] + chist[j];
+    __syncthreads();
+    // pass B: chunk-wise counting sort; fstart[f] advances as chunks are placed
+    for (uint32_t c0 = 0; c0 < m; c0 += chunk_cap) {
+        const uint32_t cm = (m - c0 < chunk_cap) ? m - c0 : chunk_cap;
+        for (uint32_t j = threadIdx.x; j < nfine; j += SORT_TPB) chist[j] = 0;
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < cm; k += SORT_TPB) atomicAdd(&chist[key[c0 + k] & fmask], 1u);
+        __syncthreads();
+        block_exclusive_scan(chist, cstart, nfine, tmp);
+        for (uint32_t j = threadIdx.x; j < nfine; j += SORT_TPB) ccur[j] = cstart[j];
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < cm; k += SORT_TPB) {
+            const uint32_t f = key[c0 + k] & fmask;
+            const uint32_t r = atomicAdd(&ccur[f], 1u);
+            st_payload[r] = pay[c0 + k];
+            st_fine[r] = (unsigned short)f;
+        }
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < cm; k += SORT_TPB) {
+            const uint32_t f = st_fine[k];
+            out[fstart[f] + (k - cstart[f])] = st_payload[k];
+        }
+        __syncthreads();
+        for (uint32_t j = threadIdx.x; j < nfine; j += SORT_TPB) fstart[j] += chist[j];
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------ accumulation
 // Work-balanced bucket accumulation.  Each lane owns S CONSECUTIVE entries of one window's
 // bucket-sorted point list, whatever buckets they fall in (a segmented sum by key with
@@ -787,6 +1001,28 @@ void l_scatter(hipStream_t st, const uint32_t* scalars, size_t n, int mont, int 
     if (!n) return;
     hipLaunchKernelGGL(k_scatter, dim3(blocks_for(n)), dim3(TPB), 0, st, scalars, n, mont, c, W, cursor, lists, list_stride);
 }
+// digits / lists may alias (digits are dead once k_sort_coarse has run)
+void l_sort(hipStream_t st, const uint32_t* scalars, size_t n, int mont, int c, int W, uint32_t* coarse,
+            uint32_t* cursor, int32_t* digits, uint32_t* tmp_payload, uint32_t* tmp_key, uint32_t* ends, uint32_t* lists,
+            size_t stride) {
+    if (!n) return;
+    const int hb = (c - 1 < SORT_MAX_HB) ? c - 1 : SORT_MAX_HB;
+    const uint32_t nbin = 1u << hb;
+    // scalars per k_sort_digits workgroup: enough workgroups for every CU, few enough global atomics
+    uint32_t per_block = 8192;
+    while (per_block > SORT_TPB && (n + per_block - 1) / per_block < 1024) per_block >>= 1;
+    hipLaunchKernelGGL(k_sort_digits, dim3((unsigned)((n + per_block - 1) / per_block)), dim3(SORT_TPB),
+                       (size_t)W * nbin * 4, st, scalars, n, mont, c, W, hb, per_block, digits, stride, coarse);
+    hipLaunchKernelGGL(k_sort_scan, dim3(W), dim3(SORT_TPB), 0, st, coarse, cursor, nbin);
+    hipLaunchKernelGGL(k_sort_coarse, dim3((unsigned)((n + SORT_TILE - 1) / SORT_TILE), W), dim3(SORT_TPB), 0, st, digits, n,
+                       stride, c, hb, cursor, tmp_payload, tmp_key);
+    // chunk capacity of k_sort_fine: about twice the expected bin size, 1K .. 16K entries
+    uint32_t chunk_cap = 1024;
+    while (chunk_cap < (uint32_t)SORT_CHUNK && chunk_cap < 2 * (n >> hb)) chunk_cap <<= 1;
+    const size_t fine_lds = ((size_t)4 << (c - 1 - hb)) * 4 + (size_t)chunk_cap * 6;
+    hipLaunchKernelGGL(k_sort_fine, dim3(nbin, W), dim3(SORT_TPB), fine_lds, st, tmp_payload, tmp_key, coarse, stride, c, hb,
+                       chunk_cap, ends, lists);
+}
 void l_accumulate(hipStream_t st, const uint32_t* ends, const uint32_t* lists, size_t list_stride, const uint32_t* bases,
                   uint32_t* buckets, uint32_t* part_first, uint32_t* part_last, uint32_t* cont_bucket,
                   uint32_t* long_queue, int W, uint32_t B, uint32_t S, uint32_t T) {
@@ -864,7 +1100,7 @@ void l_madd_bench(hipStream_t st, const uint32_t* pts, uint32_t* out, size_t nth
 
 const group_vtable g_vt = {
     GP::CURVE, GP::GROUP, FRW, EW, FR::BITS, GP::LIBFF_PROJECTIVE ? 1 : 0, FR::R,
-    l_import_bases, l_count, l_scatter, l_accumulate, l_reduce_segments, l_sum_butterfly, l_horner, l_sum_points,
+    l_import_bases, l_count, l_scatter, l_sort, l_accumulate, l_reduce_segments, l_sum_butterfly, l_horner, l_sum_points,
     l_gen_bases_seq, l_export_affine, l_ffi_decode_points, l_ffi_decode_scalars, l_ffi_encode_point, l_field_op, l_group_op, l_digits, l_mul_bench, l_madd_bench,
 };
 
