@@ -83,6 +83,26 @@ def random_scalars(curve, n, device, seed):
     return x
 
 
+def pmc_traffic(curve_name, group, log2n, window_bits):
+    """HBM bytes per k_accumulate launch from the committed rocprofv3 PMC passes
+    (profiles/r*_pmc_*.json: separate FETCH_SIZE / WRITE_SIZE runs of this very command,
+    gfx950 correction 2*FETCH + WRITE, see the file), or None when no pass matches the workload."""
+    import glob
+
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_*.json"))):
+        try:
+            d = json.load(open(path))
+            wl = d["workload"]
+            if (wl["curve"], wl["group"], wl["log2n"], wl["window_bits"]) != (curve_name, group, log2n, window_bits):
+                continue
+            k = d["kernels"]["k_accumulate"]
+            best = (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0
+        except Exception:
+            continue
+    return best
+
+
 def cpu_baseline(curve, group, log2n_sample):
     """Time the CPU path on this box: the reference's multi_exp<BDLO12_signed, special> when
     oracle/_ref/libff_ref.so is present, else the C restatement; all host cores, one range
@@ -258,7 +278,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": pmc_traffic(args.curve, group, args.log2n, plan["c"]),
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "kernel_ms": acc,
                 "note": "integer-ALU bound path (no MFMA); HBM fraction is small by construction",

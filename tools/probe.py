@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import libff_amd  # noqa: E402
 
 GROUPS = [("alt_bn128_g1", 0, 1), ("bls12_377_g1", 1, 1), ("bw6_761_g1", 2, 1), ("alt_bn128_g2", 0, 2),
-          ("bls12_377_g2", 1, 2)]
+          ("bls12_377_g2", 1, 2), ("bw6_761_g2", 2, 2)]
 
 
 def main():
@@ -27,7 +27,7 @@ def main():
         eng.h2d(d_aff, aff)
         d_out = eng.malloc(nthreads * s["g_bytes"])
         fq_words = s["affine_bytes"] // 8 // (2 if group == 2 and curve != 2 else 1)
-        for variant in ((0, 1) if name == "alt_bn128_g1" else (0,)):
+        for variant in (0, 1):
             ms = ctypes.c_float(0)
             iters = 64
             for _ in range(2):
