@@ -148,6 +148,12 @@ def main():
     ap.add_argument("--extra-log2n", type=int, default=int(os.environ.get("AMDMSM_BENCH_EXTRA_LOG2N", "26")),
                     help="also time this size after the main region (reported under 'also'); 0 disables")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pipeline", type=int, default=int(os.environ.get("AMDMSM_BENCH_PIPELINE", "1")),
+                    help="MSMs in flight in the timed region (1 = strictly one after the other, which is "
+                         "what `value` and the roofline kernel timings are quoted on)")
+    ap.add_argument("--also-pipelined", type=int, default=2,
+                    help="after the timed region, also measure the same workload with this many MSMs in flight "
+                         "(reported under 'pipelined'); 0 disables")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -179,26 +185,36 @@ def main():
     scalars = random_scalars(curve, n, dev, seed=1234 + rank)
     torch.cuda.synchronize()
 
-    msm = ShardedMsm(eng, curve, group)
+    msm = ShardedMsm(eng, curve, group, depth=max(1, args.pipeline))
     eng.set_timing(True)
 
     def step():
         return msm.run(bases, scalars, n, libff_amd.OUT_LIBFF, window_bits=args.window_bits)
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, msm.depth if args.warmup else 0)):
         step()
+    msm.synchronize()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     acc_ms = []
     phases = []
+    pending = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
-        t = eng.get_timings()          # waits for this step's kernels on the launch stream
+        _, slot = step()
+        pending.append(slot)
+        # read the HIP-event timings of a step only once a later step is already enqueued
+        while len(pending) >= msm.depth:
+            t = eng.get_timings(pending.pop(0))
+            acc_ms.append(t["accumulate_ms"])
+            phases.append(t)
+    while pending:
+        t = eng.get_timings(pending.pop(0))
         acc_ms.append(t["accumulate_ms"])
         phases.append(t)
+    msm.synchronize()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -208,6 +224,36 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+
+    # ---- same workload with several MSMs in flight (throughput of back-to-back MSMs) ----
+    pipelined = None
+    if args.also_pipelined > 1 and msm.depth == 1:
+        pm = ShardedMsm(eng, curve, group, depth=args.also_pipelined)
+        for _ in range(pm.depth):
+            pm.run(bases, scalars, n, libff_amd.OUT_LIBFF, window_bits=args.window_bits)
+        pm.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        kp = max(args.steps, 2 * pm.depth)
+        tp = time.perf_counter()
+        for _ in range(kp):
+            pm.run(bases, scalars, n, libff_amd.OUT_LIBFF, window_bits=args.window_bits)
+        pm.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        ep = time.perf_counter() - tp
+        if world > 1:
+            tt = torch.tensor([ep], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            ep = float(tt.item())
+        pipelined = {"msms_in_flight": pm.depth, "steps": kp, "value": n * world * kp / ep, "unit": "scalar-muls/s",
+                     "ms_per_step": ep / kp * 1e3,
+                     "note": "consecutive MSMs issued on alternating streams / workspace slots so the few-wave "
+                             "tail of one overlaps the bulk kernels of the next; per-kernel timings are not "
+                             "comparable with the un-overlapped ones, so `value` stays the depth-1 figure"}
+        msm = ShardedMsm(eng, curve, group, depth=1)
 
     # ---- second size of the metric (2^26 by default), outside the main timed region ----
     also = None
@@ -219,15 +265,18 @@ def main():
         eng.gen_bases_seq_device(curve, group, rank * n2, n2, bases2.data_ptr(), stream=stream)
         scalars2 = random_scalars(curve, n2, dev, seed=4321 + rank)
         torch.cuda.synchronize()
-        msm.run(bases2, scalars2, n2, libff_amd.OUT_LIBFF)
+        for _ in range(msm.depth):
+            msm.run(bases2, scalars2, n2, libff_amd.OUT_LIBFF)
+        msm.synchronize()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        k2 = 3
+        k2 = 4
         t1 = time.perf_counter()
         for _ in range(k2):
-            msm.run(bases2, scalars2, n2, libff_amd.OUT_LIBFF)
-            ph2 = eng.get_timings()
+            _, slot2 = msm.run(bases2, scalars2, n2, libff_amd.OUT_LIBFF)
+        ph2 = eng.get_timings(slot2)
+        msm.synchronize()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -270,6 +319,7 @@ def main():
                 "window_bits": plan["c"],
                 "num_windows": plan["num_windows"],
                 "parallelism": f"range-sharded x{world}, all-gather of partial points + local sum",
+                "msms_in_flight": msm.depth,
             },
             "roofline": {
                 "bound": "hbm",
@@ -285,6 +335,8 @@ def main():
             },
             "phases_ms": mean_phase,
         }
+        if pipelined is not None:
+            out["pipelined"] = pipelined
         if also is not None:
             out["also"] = also
         if world == 1 and not args.no_cpu_baseline:

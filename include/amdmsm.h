@@ -128,10 +128,21 @@ int amdmsm_sum_points_device(amdmsm_ctx *ctx, int curve, int group, const void *
 int amdmsm_gen_bases_seq_device(amdmsm_ctx *ctx, int curve, int group, uint64_t first, size_t n,
                                 void *d_dst_affine, void *stream);
 
+/* ---- MSMs in flight ----
+ * depth = number of workspace slots (1..4, default 1) taken round-robin by consecutive
+ * amdmsm_msm_device calls.  With depth > 1, calls issued on DIFFERENT streams may overlap on
+ * the device (a prover's back-to-back MSMs: the few-wave tail of one under the bulk kernels
+ * of the next); a slot is reused only after its previous call has completed. */
+int amdmsm_set_pipeline_depth(amdmsm_ctx *ctx, int depth);
+/* slot used by the most recent amdmsm_msm_device call */
+int amdmsm_last_slot(amdmsm_ctx *ctx);
+
 /* ---- per-phase device timing (hipEvents on the launch stream) ---- */
 int amdmsm_set_timing(amdmsm_ctx *ctx, int enable);
-/* milliseconds of the most recent amdmsm_msm_device call; synchronises its stream */
+/* milliseconds of the most recent amdmsm_msm_device call; waits for that call */
 int amdmsm_get_timings(amdmsm_ctx *ctx, float ms[AMDMSM_MAX_PHASES]);
+/* same for the call that last used workspace slot `slot` */
+int amdmsm_get_slot_timings(amdmsm_ctx *ctx, int slot, float ms[AMDMSM_MAX_PHASES]);
 
 /* ---- parity-test hooks for the primitives (device pointers) ---- */
 int amdmsm_field_op_device(amdmsm_ctx *ctx, int curve, int group, int op, const void *d_a,

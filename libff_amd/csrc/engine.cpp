@@ -17,15 +17,29 @@
 
 using namespace amdmsm;
 
+// One workspace "slot" per MSM in flight.  With pipeline depth > 1 consecutive
+// amdmsm_msm_device calls take the slots round-robin, so calls issued on different streams
+// may overlap on the device (the small-grid tail of one MSM under the bulk kernels of the
+// next); a slot is reused only after the call that last used it has finished (event wait).
+constexpr int MAX_SLOTS = 4;
+struct ws_slot {
+    void *ws = nullptr;
+    size_t ws_bytes = 0;
+    hipEvent_t done = nullptr;
+    bool used = false;
+    hipEvent_t ev[AMDMSM_MAX_PHASES + 1] = {};
+    bool ev_valid = false;
+};
+
 struct amdmsm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    void *ws = nullptr;
-    size_t ws_bytes = 0;
+    ws_slot slots[MAX_SLOTS];
+    int depth = 1;
+    unsigned next = 0;
+    int last_slot = 0;
     bool timing = false;
-    hipEvent_t ev[AMDMSM_MAX_PHASES + 1] = {};
-    bool ev_valid = false;
-    hipStream_t ev_stream = nullptr;
+    hipEvent_t ev[AMDMSM_MAX_PHASES + 1] = {};   // probes
     std::string err;
     std::mutex mu;
 };
@@ -160,17 +174,17 @@ int make_plan(const group_vtable *vt, size_t n, int c_req, int L_req, plan_t &p,
     return AMDMSM_OK;
 }
 
-int ensure_ws(amdmsm_ctx *ctx, size_t bytes) {
-    if (ctx->ws_bytes >= bytes) return AMDMSM_OK;
-    if (ctx->ws) {
+int ensure_ws(amdmsm_ctx *ctx, ws_slot &sl, size_t bytes) {
+    if (sl.ws_bytes >= bytes) return AMDMSM_OK;
+    if (sl.ws) {
         HIP_TRY(ctx, hipDeviceSynchronize());
-        HIP_TRY(ctx, hipFree(ctx->ws));
-        ctx->ws = nullptr;
-        ctx->ws_bytes = 0;
+        HIP_TRY(ctx, hipFree(sl.ws));
+        sl.ws = nullptr;
+        sl.ws_bytes = 0;
     }
     const size_t want = bytes + bytes / 8;
-    HIP_TRY(ctx, hipMalloc(&ctx->ws, want));
-    ctx->ws_bytes = want;
+    HIP_TRY(ctx, hipMalloc(&sl.ws, want));
+    sl.ws_bytes = want;
     return AMDMSM_OK;
 }
 
@@ -186,8 +200,8 @@ struct dev_guard {
     }
 };
 
-void record(amdmsm_ctx *ctx, int idx, hipStream_t st) {
-    if (ctx->timing) (void)hipEventRecord(ctx->ev[idx], st);
+void record(amdmsm_ctx *ctx, ws_slot &sl, int idx, hipStream_t st) {
+    if (ctx->timing) (void)hipEventRecord(sl.ev[idx], st);
 }
 
 // The whole single-GPU MSM on device-resident inputs.
@@ -208,37 +222,40 @@ int msm_device_impl(amdmsm_ctx *ctx, const group_vtable *vt, const uint32_t *d_b
     static const int acc_s_env = getenv("AMDMSM_ACC_S") ? atoi(getenv("AMDMSM_ACC_S")) : 0;
     int rc = make_plan(vt, n, opts ? opts->window_bits : 0, opts ? opts->segment_len : 0, p, acc_s_env);
     if (rc) return fail(ctx, rc, "bad window_bits / segment_len");
-    rc = ensure_ws(ctx, p.total);
+    const int slot_idx = (int)(ctx->next++ % (unsigned)ctx->depth);
+    ws_slot &sl = ctx->slots[slot_idx];
+    ctx->last_slot = slot_idx;
+    if (sl.used) HIP_TRY(ctx, hipStreamWaitEvent(st, sl.done, 0));   // previous user of this slot
+    rc = ensure_ws(ctx, sl, p.total);
     if (rc) return rc;
-    char *ws = (char *)ctx->ws;
+    char *ws = (char *)sl.ws;
     uint32_t *counts = (uint32_t *)(ws + p.off_counts);
     uint32_t *lists = (uint32_t *)(ws + p.off_lists);
     uint32_t *buckets = (uint32_t *)(ws + p.off_buckets);
     uint32_t *lvl0 = (uint32_t *)(ws + p.off_lvl0);
     uint32_t *lvl1 = (uint32_t *)(ws + p.off_lvl1);
 
-    ctx->ev_stream = st;
-    record(ctx, 0, st);
+    record(ctx, sl, 0, st);
     static const bool atomic_sort = getenv("AMDMSM_SORT") && !strcmp(getenv("AMDMSM_SORT"), "atomic");
     if (atomic_sort || p.c > 22) {
         HIP_TRY(ctx, hipMemsetAsync(counts, 0, (size_t)p.W * p.B * 4, st));
         vt->count(st, d_scalars, n, mont, p.c, p.W, counts);
-        record(ctx, 1, st);
+        record(ctx, sl, 1, st);
         vt->scatter(st, d_scalars, n, mont, p.c, p.W, counts, lists, p.list_stride);
     } else {
         HIP_TRY(ctx, hipMemsetAsync(ws + p.off_coarse, 0, (size_t)p.W * 1025 * 4, st));
-        record(ctx, 1, st);
+        record(ctx, sl, 1, st);
         vt->sort(st, d_scalars, n, mont, p.c, p.W, (uint32_t *)(ws + p.off_coarse), (uint32_t *)(ws + p.off_cursor),
                  (int32_t *)lists, (uint32_t *)(ws + p.off_tmp_payload), (uint32_t *)(ws + p.off_tmp_key), counts, lists,
                  p.list_stride);
     }
-    record(ctx, 2, st);
+    record(ctx, sl, 2, st);
     HIP_TRY(ctx, hipMemsetAsync(buckets, 0, (size_t)p.W * p.B * vt->el_words * 12, st));
     HIP_TRY(ctx, hipMemsetAsync(ws + p.off_queue, 0, 8, st));
     vt->accumulate(st, counts, lists, p.list_stride, d_bases, buckets, (uint32_t *)(ws + p.off_pfirst),
                    (uint32_t *)(ws + p.off_plast), (uint32_t *)(ws + p.off_cont), (uint32_t *)(ws + p.off_queue), p.W,
                    p.B, p.S, p.T);
-    record(ctx, 3, st);
+    record(ctx, sl, 3, st);
     vt->reduce_segments(st, buckets, p.W, p.B, p.L, lvl0);
     uint32_t M = p.B / p.L;
     M /= std::min<uint32_t>(M, 64u);   // folded per wave inside reduce_segments
@@ -248,10 +265,12 @@ int msm_device_impl(amdmsm_ctx *ctx, const group_vtable *vt, const uint32_t *d_b
         M /= std::min<uint32_t>(M, 64u);
         std::swap(src, dst);
     }
-    record(ctx, 4, st);
+    record(ctx, sl, 4, st);
     vt->horner(st, src, p.W, p.c, form, d_out);
-    record(ctx, 5, st);
-    ctx->ev_valid = ctx->timing;
+    record(ctx, sl, 5, st);
+    sl.ev_valid = ctx->timing;
+    HIP_TRY(ctx, hipEventRecord(sl.done, st));
+    sl.used = true;
     HIP_TRY(ctx, hipGetLastError());
     return AMDMSM_OK;
 }
@@ -302,6 +321,14 @@ int amdmsm_ctx_create(int device, amdmsm_ctx **out) {
             return AMDMSM_ERR_HIP;
         }
     }
+    for (auto &sl : ctx->slots) {
+        bool ok = hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) == hipSuccess;
+        for (auto &e : sl.ev) ok = ok && hipEventCreate(&e) == hipSuccess;
+        if (!ok) {
+            delete ctx;
+            return AMDMSM_ERR_HIP;
+        }
+    }
     *out = ctx;
     return AMDMSM_OK;
 }
@@ -311,7 +338,13 @@ void amdmsm_ctx_destroy(amdmsm_ctx *ctx) {
     {
         dev_guard g(ctx->device);
         (void)hipDeviceSynchronize();
-        if (ctx->ws) (void)hipFree(ctx->ws);
+        for (auto &sl : ctx->slots) {
+            if (sl.ws) (void)hipFree(sl.ws);
+            if (sl.done) (void)hipEventDestroy(sl.done);
+            for (auto &e : sl.ev) {
+                if (e) (void)hipEventDestroy(e);
+            }
+        }
         for (auto &e : ctx->ev) {
             if (e) (void)hipEventDestroy(e);
         }
@@ -357,19 +390,37 @@ size_t amdmsm_bdlo12_signed_optimal_c(size_t num_elements) {
 int amdmsm_set_timing(amdmsm_ctx *ctx, int enable) {
     if (!ctx) return AMDMSM_ERR_BAD_ARG;
     ctx->timing = enable != 0;
-    ctx->ev_valid = false;
+    for (auto &sl : ctx->slots) sl.ev_valid = false;
+    return AMDMSM_OK;
+}
+
+int amdmsm_set_pipeline_depth(amdmsm_ctx *ctx, int depth) {
+    if (!ctx || depth < 1 || depth > MAX_SLOTS) return AMDMSM_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    dev_guard g(ctx->device);
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    ctx->depth = depth;
+    ctx->next = 0;
+    return AMDMSM_OK;
+}
+
+int amdmsm_last_slot(amdmsm_ctx *ctx) { return ctx ? ctx->last_slot : AMDMSM_ERR_BAD_ARG; }
+
+int amdmsm_get_slot_timings(amdmsm_ctx *ctx, int slot, float ms[AMDMSM_MAX_PHASES]) {
+    if (!ctx || !ms || slot < 0 || slot >= MAX_SLOTS) return AMDMSM_ERR_BAD_ARG;
+    for (int i = 0; i < AMDMSM_MAX_PHASES; ++i) ms[i] = 0.f;
+    ws_slot &sl = ctx->slots[slot];
+    if (!sl.ev_valid) return fail(ctx, AMDMSM_ERR_BAD_ARG, "no timed amdmsm_msm_device call recorded in this slot");
+    dev_guard g(ctx->device);
+    HIP_TRY(ctx, hipEventSynchronize(sl.ev[5]));
+    for (int i = 0; i < 5; ++i) HIP_TRY(ctx, hipEventElapsedTime(&ms[i], sl.ev[i], sl.ev[i + 1]));
+    HIP_TRY(ctx, hipEventElapsedTime(&ms[AMDMSM_PH_TOTAL], sl.ev[0], sl.ev[5]));
     return AMDMSM_OK;
 }
 
 int amdmsm_get_timings(amdmsm_ctx *ctx, float ms[AMDMSM_MAX_PHASES]) {
-    if (!ctx || !ms) return AMDMSM_ERR_BAD_ARG;
-    for (int i = 0; i < AMDMSM_MAX_PHASES; ++i) ms[i] = 0.f;
-    if (!ctx->ev_valid) return fail(ctx, AMDMSM_ERR_BAD_ARG, "no timed amdmsm_msm_device call recorded");
-    dev_guard g(ctx->device);
-    HIP_TRY(ctx, hipEventSynchronize(ctx->ev[5]));
-    for (int i = 0; i < 5; ++i) HIP_TRY(ctx, hipEventElapsedTime(&ms[i], ctx->ev[i], ctx->ev[i + 1]));
-    HIP_TRY(ctx, hipEventElapsedTime(&ms[AMDMSM_PH_TOTAL], ctx->ev[0], ctx->ev[5]));
-    return AMDMSM_OK;
+    if (!ctx) return AMDMSM_ERR_BAD_ARG;
+    return amdmsm_get_slot_timings(ctx, ctx->last_slot, ms);
 }
 
 #define GET_VT(ctx, curve, group)                                         \

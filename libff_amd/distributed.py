@@ -44,9 +44,14 @@ def sharded_multi_exp(local_msm, combine, group=None):
 
 class ShardedMsm:
     """Device-resident sharded MSM for one (curve, group): each rank holds its own range of
-    compact-affine bases and Montgomery scalars in HBM as torch tensors."""
+    compact-affine bases and Montgomery scalars in HBM as torch tensors.
 
-    def __init__(self, engine, curve, group_id, process_group=None):
+    ``depth`` > 1 keeps that many MSMs in flight: step k runs on stream ``k % depth`` with its own
+    workspace slot and result buffers, so the few-wave tail (bucket reduction, Horner) of one
+    step overlaps the bulk kernels of the next -- the way a prover issues its back-to-back MSMs.
+    """
+
+    def __init__(self, engine, curve, group_id, process_group=None, depth=1):
         import torch
 
         self.torch = torch
@@ -54,32 +59,47 @@ class ShardedMsm:
         self.curve = curve
         self.group_id = group_id
         self.pg = process_group
+        self.depth = depth
         from .engine import sizes
 
         self.sz = sizes(curve, group_id)
         dev = torch.device("cuda", engine.device)
-        self.partial = torch.zeros(self.sz["g_bytes"] // 8, dtype=torch.int64, device=dev)
-        self.result = torch.zeros(self.sz["g_bytes"] // 8, dtype=torch.int64, device=dev)
+        words = self.sz["g_bytes"] // 8
+        self.partial = [torch.zeros(words, dtype=torch.int64, device=dev) for _ in range(depth)]
+        self.result = [torch.zeros(words, dtype=torch.int64, device=dev) for _ in range(depth)]
+        self.streams = [torch.cuda.current_stream(dev)] if depth == 1 else [torch.cuda.Stream(dev) for _ in range(depth)]
+        self.k = 0
+        engine.set_pipeline_depth(depth)
 
     def run(self, bases_affine, scalars, n, out_form, window_bits=0):
-        """bases_affine / scalars: this rank's shard (torch tensors on its GPU)."""
+        """bases_affine / scalars: this rank's shard (torch tensors on its GPU).  Returns
+        (result tensor, workspace slot); with depth > 1 the result is ready once the step's
+        stream has been synchronised (``synchronize()``)."""
         from .engine import OUT_JACOBIAN
-
-        torch = self.torch
-        stream = torch.cuda.current_stream().cuda_stream
-        self.engine.msm_device(self.curve, self.group_id, bases_affine.data_ptr(), scalars.data_ptr(), n,
-                               self.partial.data_ptr(), out_form=OUT_JACOBIAN, window_bits=window_bits,
-                               stream=stream)
         import torch.distributed as dist
 
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.pg) > 1:
-            stacked = all_gather_partials(self.partial, group=self.pg).contiguous()
-            k = stacked.shape[0]
-        else:
-            stacked, k = self.partial, 1
-        self.engine.sum_points_device(self.curve, self.group_id, stacked.data_ptr(), k, out_form,
-                                      self.result.data_ptr(), stream=stream)
-        return self.result
+        torch = self.torch
+        i = self.k % self.depth
+        self.k += 1
+        stream = self.streams[i]
+        partial, result = self.partial[i], self.result[i]
+        with torch.cuda.stream(stream):
+            self.engine.msm_device(self.curve, self.group_id, bases_affine.data_ptr(), scalars.data_ptr(), n,
+                                   partial.data_ptr(), out_form=OUT_JACOBIAN, window_bits=window_bits,
+                                   stream=stream.cuda_stream)
+            slot = self.engine.last_slot()
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.pg) > 1:
+                stacked = all_gather_partials(partial, group=self.pg).contiguous()
+                k = stacked.shape[0]
+            else:
+                stacked, k = partial, 1
+            self.engine.sum_points_device(self.curve, self.group_id, stacked.data_ptr(), k, out_form,
+                                          result.data_ptr(), stream=stream.cuda_stream)
+        return result, slot
+
+    def synchronize(self):
+        for s in self.streams:
+            s.synchronize()
 
 
 def numpy_words(t):

@@ -44,7 +44,8 @@ EXPORTED_SYMBOLS = [
     "amdmsm_bdlo12_signed_optimal_c", "amdmsm_multi_exp", "amdmsm_multi_exp_filter_one_zero",
     "amdmsm_batch_to_special", "amdmsm_import_bases_device", "amdmsm_export_affine_device",
     "amdmsm_msm_device", "amdmsm_sum_points_device", "amdmsm_gen_bases_seq_device",
-    "amdmsm_set_timing", "amdmsm_get_timings", "amdmsm_field_op_device", "amdmsm_group_op_device",
+    "amdmsm_set_timing", "amdmsm_get_timings", "amdmsm_set_pipeline_depth", "amdmsm_last_slot",
+    "amdmsm_get_slot_timings", "amdmsm_field_op_device", "amdmsm_group_op_device",
     "amdmsm_digits_device", "amdmsm_mul_bench_device", "amdmsm_madd_bench_device", "amdmsm_malloc", "amdmsm_free",
     "amdmsm_memcpy_h2d", "amdmsm_memcpy_d2h", "amdmsm_synchronize",
 ]
@@ -287,9 +288,19 @@ class Engine:
     def set_timing(self, enable=True):
         self._check(self.lib.amdmsm_set_timing(self.h, int(enable)), "amdmsm_set_timing")
 
-    def get_timings(self):
+    def set_pipeline_depth(self, depth):
+        """Number of MSMs that may be in flight (workspace slots, 1..4); see include/amdmsm.h."""
+        self._check(self.lib.amdmsm_set_pipeline_depth(self.h, int(depth)), "amdmsm_set_pipeline_depth")
+
+    def last_slot(self):
+        return int(self.lib.amdmsm_last_slot(self.h))
+
+    def get_timings(self, slot=None):
         ms = (ctypes.c_float * MAX_PHASES)()
-        self._check(self.lib.amdmsm_get_timings(self.h, ms), "amdmsm_get_timings")
+        if slot is None:
+            self._check(self.lib.amdmsm_get_timings(self.h, ms), "amdmsm_get_timings")
+        else:
+            self._check(self.lib.amdmsm_get_slot_timings(self.h, int(slot), ms), "amdmsm_get_slot_timings")
         return {"count_ms": ms[PH_COUNT], "scatter_ms": ms[PH_SCATTER], "accumulate_ms": ms[PH_ACCUM],
                 "reduce_ms": ms[PH_REDUCE], "final_ms": ms[PH_FINAL], "total_ms": ms[PH_TOTAL]}
 
