@@ -12,6 +12,8 @@
  *                             multiexp.tcc:690-757
  *   amdmsm_batch_to_special   libff::batch_to_special<G>, multiexp.hpp:136-141,
  *                             multiexp.tcc:949-974
+ *   amdmsm_batch_exp          libff::get_window_table + batch_exp / batch_exp_with_coeff,
+ *                             multiexp.hpp:99-134, multiexp.tcc:809-947
  *   amdmsm_bdlo12_signed_optimal_c / amdmsm_pippenger_optimal_c
  *                             multiexp.hpp:53-57, multiexp.tcc:35-40, 637-641
  *   amdmsm_*_device           the same path for callers whose vectors already live in
@@ -112,6 +114,15 @@ int amdmsm_multi_exp_filter_one_zero(amdmsm_ctx *ctx, int curve, int group,
 
 int amdmsm_batch_to_special(amdmsm_ctx *ctx, int curve, int group, void *elems_xyz,
                             size_t stride_bytes, size_t n);
+
+/* Fixed-base batch exponentiation: out[i] = scalars[i] * g (or (coeff * scalars[i]) * g when
+ * coeff != NULL), i < n, through a window table built on the device.  Replaces
+ * get_window_table + batch_exp / batch_exp_with_coeff (multiexp.hpp:99-134,
+ * multiexp.tcc:809-947); `scalar_size` and `window` have the reference's meaning
+ * (FieldT::size_in_bits(), get_exp_window_size).  out: n packed (X, Y, Z) records. */
+int amdmsm_batch_exp(amdmsm_ctx *ctx, int curve, int group, size_t scalar_size, size_t window,
+                     const void *g_xyz, const void *scalars, size_t n, const void *coeff,
+                     int scalars_plain, void *out_xyz);
 
 /* ---- device-resident entry points (all pointers are HBM addresses) ---- */
 int amdmsm_import_bases_device(amdmsm_ctx *ctx, int curve, int group, const void *d_src_xyz,

@@ -13,8 +13,11 @@
 // below fix GroupT/FieldT as well, are therefore more specialised, and are picked for
 //   alt_bn128_G1/G2, bls12_377_G1/G2, bw6_761_G1/G2
 // while every other (group, method) pair keeps the reference's CPU body.  multi_exp itself
-// (chunk split + serial sum, multiexp.tcc:643-688), multi_exp_filter_one_zero (:690-757) and
-// batch_exp & co. are the reference's own code and simply call into the engine per chunk.
+// (chunk split + serial sum, multiexp.tcc:643-688) and multi_exp_filter_one_zero (:690-757) are
+// the reference's own code and simply call into the engine per chunk.  Fixed-base
+// batch_exp / batch_exp_with_coeff (multiexp.tcc:874-947) get non-template overloads for the
+// same groups (chosen over the templates when the call deduces its arguments, as libsnark's
+// key generators do); explicit batch_exp<T, FieldT>(...) calls keep the CPU body.
 //
 // Data crosses the boundary without conversion: &*vec_start is handed to the C ABI as the
 // libff in-memory records (Montgomery limbs, (X, Y, Z)), sizeof(T) is the stride.
@@ -99,6 +102,41 @@ GroupT gpu_multi_exp_inner(
     return result;
 }
 
+/// batch_exp / batch_exp_with_coeff (multiexp.tcc:874-947) on the device.  The window table
+/// libff built on the host (get_window_table, multiexp.tcc:809-846) is only read for its
+/// generator, powers_of_g[0][1] = g; the device rebuilds the table in HBM.
+template<typename GroupT, typename FieldT>
+std::vector<GroupT> gpu_batch_exp(
+    const size_t scalar_size,
+    const size_t window,
+    const libff::window_table<GroupT> &table,
+    const FieldT *coeff,
+    const std::vector<FieldT> &v,
+    const size_t num_entries)
+{
+    std::vector<GroupT> res(num_entries, GroupT::zero());
+    const GroupT &g = table.at(0).at(1);
+    const int rc = amdmsm_batch_exp(
+        default_context(),
+        group_id<GroupT>::curve,
+        group_id<GroupT>::group,
+        scalar_size,
+        window,
+        static_cast<const void *>(&g.X),
+        num_entries ? static_cast<const void *>(v.data()) : nullptr,
+        num_entries,
+        static_cast<const void *>(coeff),
+        0,
+        num_entries ? static_cast<void *>(&res[0].X) : nullptr);
+    if (rc != AMDMSM_OK) {
+        throw std::runtime_error(
+            std::string("libff_amd: amdmsm_batch_exp failed: ") +
+            amdmsm_strerror(rc) + " (" +
+            amdmsm_last_error(default_context()) + ")");
+    }
+    return res;
+}
+
 } // namespace libff_amd
 
 /// Route BDLO12 and BDLO12_signed of one (GroupT, FieldT) pair to the engine.
@@ -150,6 +188,35 @@ GroupT gpu_multi_exp_inner(
                 bases, bases_end, exponents, exponents_end);                   \
         }                                                                      \
     };                                                                         \
+    }                                                                          \
+    inline std::vector<GROUP_T> batch_exp(                                     \
+        const size_t scalar_size,                                              \
+        const size_t window,                                                   \
+        const window_table<GROUP_T> &table,                                    \
+        const std::vector<FIELD_T> &v)                                         \
+    {                                                                          \
+        return libff_amd::gpu_batch_exp<GROUP_T, FIELD_T>(                     \
+            scalar_size, window, table, nullptr, v, v.size());                 \
+    }                                                                          \
+    inline std::vector<GROUP_T> batch_exp(                                     \
+        const size_t scalar_size,                                              \
+        const size_t window,                                                   \
+        const window_table<GROUP_T> &table,                                    \
+        const std::vector<FIELD_T> &v,                                         \
+        size_t num_entries)                                                    \
+    {                                                                          \
+        return libff_amd::gpu_batch_exp<GROUP_T, FIELD_T>(                     \
+            scalar_size, window, table, nullptr, v, num_entries);              \
+    }                                                                          \
+    inline std::vector<GROUP_T> batch_exp_with_coeff(                          \
+        const size_t scalar_size,                                              \
+        const size_t window,                                                   \
+        const window_table<GROUP_T> &table,                                    \
+        const FIELD_T &coeff,                                                  \
+        const std::vector<FIELD_T> &v)                                         \
+    {                                                                          \
+        return libff_amd::gpu_batch_exp<GROUP_T, FIELD_T>(                     \
+            scalar_size, window, table, &coeff, v, v.size());                  \
     }                                                                          \
     }
 

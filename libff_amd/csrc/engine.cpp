@@ -642,6 +642,52 @@ int amdmsm_multi_exp_filter_one_zero(amdmsm_ctx *ctx, int curve, int group, cons
     return amdmsm_multi_exp(ctx, curve, group, bases_xyz, base_stride_bytes, base_form, scalars, n, out_xyz, opts);
 }
 
+int amdmsm_batch_exp(amdmsm_ctx *ctx, int curve, int group, size_t scalar_size, size_t window, const void *g_xyz,
+                     const void *scalars, size_t n, const void *coeff, int scalars_plain, void *out_xyz) {
+    GET_VT(ctx, curve, group);
+    if (!g_xyz || (n && (!scalars || !out_xyz))) return fail(ctx, AMDMSM_ERR_BAD_ARG, "null pointer");
+    if (window < 1 || window > 22 || scalar_size < 1 || scalar_size > (size_t)vt->fr_words * 32) {
+        return fail(ctx, AMDMSM_ERR_BAD_ARG, "window / scalar_size");
+    }
+    const size_t xyz_bytes = (size_t)vt->el_words * 12, fr_bytes = (size_t)vt->fr_words * 4;
+    const size_t outerc = (scalar_size + window - 1) / window;
+    hipStream_t st = ctx->stream;
+    void *d_g = nullptr, *d_go = nullptr, *d_tab = nullptr, *d_sc = nullptr, *d_cf = nullptr, *d_out = nullptr;
+    auto cleanup = [&]() {
+        for (void *p : {d_g, d_go, d_tab, d_sc, d_cf, d_out}) {
+            if (p) (void)hipFree(p);
+        }
+    };
+#define TRY_CLEAN(expr)                                                                          \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess) {                                                                  \
+            cleanup();                                                                           \
+            return fail(ctx, AMDMSM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+        }                                                                                        \
+    } while (0)
+    TRY_CLEAN(hipMalloc(&d_g, xyz_bytes));
+    TRY_CLEAN(hipMalloc(&d_go, outerc * xyz_bytes));
+    TRY_CLEAN(hipMalloc(&d_tab, (outerc << window) * xyz_bytes));
+    TRY_CLEAN(hipMalloc(&d_sc, n ? n * fr_bytes : 16));
+    TRY_CLEAN(hipMalloc(&d_out, n ? n * xyz_bytes : 16));
+    TRY_CLEAN(hipMemcpyAsync(d_g, g_xyz, xyz_bytes, hipMemcpyHostToDevice, st));
+    if (n) TRY_CLEAN(hipMemcpyAsync(d_sc, scalars, n * fr_bytes, hipMemcpyHostToDevice, st));
+    if (coeff) {
+        TRY_CLEAN(hipMalloc(&d_cf, fr_bytes));
+        TRY_CLEAN(hipMemcpyAsync(d_cf, coeff, fr_bytes, hipMemcpyHostToDevice, st));
+    }
+    vt->fixed_base_exp(st, (const uint32_t *)d_g, (int)scalar_size, (int)window, (const uint32_t *)d_sc, n,
+                       scalars_plain ? 0 : 1, (const uint32_t *)d_cf, AMDMSM_OUT_LIBFF, (uint32_t *)d_go,
+                       (uint32_t *)d_tab, (uint32_t *)d_out);
+    TRY_CLEAN(hipGetLastError());
+    if (n) TRY_CLEAN(hipMemcpyAsync(out_xyz, d_out, n * xyz_bytes, hipMemcpyDeviceToHost, st));
+    TRY_CLEAN(hipStreamSynchronize(st));
+    cleanup();
+    return AMDMSM_OK;
+#undef TRY_CLEAN
+}
+
 int amdmsm_batch_to_special(amdmsm_ctx *ctx, int curve, int group, void *elems_xyz, size_t stride_bytes, size_t n) {
     GET_VT(ctx, curve, group);
     const size_t xyz_bytes = (size_t)vt->el_words * 12, aff_bytes = (size_t)vt->el_words * 8;

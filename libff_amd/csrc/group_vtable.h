@@ -64,6 +64,13 @@ struct group_vtable {
     void (*ffi_decode_scalars)(hipStream_t, const uint32_t* src_be, size_t n, uint32_t* dst_plain, uint32_t* status);
     void (*ffi_encode_point)(hipStream_t, const uint32_t* src_xyz_affine, uint32_t* dst_be);
 
+    // fixed-base batch exponentiation: out[i] = (coeff *) scalars[i] * g via a window table
+    // (get_window_table / windowed_exp / batch_exp[_with_coeff], multiexp.tcc:809-947);
+    // gouter: outerc points, table: outerc * 2^window points, outerc = ceil(scalar_size / window)
+    void (*fixed_base_exp)(hipStream_t, const uint32_t* g_xyz, int scalar_size, int window, const uint32_t* scalars,
+                           size_t n, int mont, const uint32_t* coeff, int form, uint32_t* gouter, uint32_t* table,
+                           uint32_t* out);
+
     // ---- test hooks (parity of the primitives against the oracle) ----------
     // coordinate-field op over arrays: 0 mul 1 sqr 2 add 3 sub 4 neg 5 inverse
     void (*field_op)(hipStream_t, int op, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t n);

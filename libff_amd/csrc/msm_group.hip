@@ -784,6 +784,104 @@ __global__ void __launch_bounds__(TPB) k_gen_bases_seq(unsigned long long first,
     store_aff(dst + i * AFFW, a);
 }
 
+// ------------------------------------------------- fixed-base exponentiation
+// batch_exp / batch_exp_with_coeff (multiexp.tcc:874-947): res[i] = v[i] * g through a window
+// table powers_of_g[outer][inner] = inner * 2^(outer*window) * g (get_window_table,
+// multiexp.tcc:809-846; the last row is shorter).  The reference builds each row with 2^window
+// serial additions; here row `outer` grows by binary splitting -- entry j = 2 * entry[j/2]
+// (+ gouter if j is odd), one launch per bit -- and the per-scalar loop (windowed_exp,
+// multiexp.tcc:848-872) is one lane per scalar.
+__global__ void __launch_bounds__(64) k_fb_gouter(const uint32_t* __restrict__ g_xyz, int outerc, int window,
+                                                  uint32_t* __restrict__ gouter) {
+    Jac<E> p;
+    load_libff(p, g_xyz);
+    for (int outer = 0; outer < outerc; ++outer) {
+        if (threadIdx.x == 0) store_jac(gouter + (size_t)outer * XYZW, p);
+        for (int i = 0; i < window; ++i) jac_dbl_lanes3(p);
+    }
+}
+
+// level `bit` (0 = top bit of the window): fills entries [2^bit, 2^(bit+1)) of every row from
+// entries [2^(bit-1), 2^bit); level 0 writes entries 0 (zero) and 1 (gouter).
+__global__ void __launch_bounds__(TPB) k_fb_table_level(const uint32_t* __restrict__ gouter, int outerc, int window,
+                                                        int scalar_size, int level, uint32_t* __restrict__ table) {
+    const size_t t = gtid();
+    const size_t row_len = (size_t)1 << window;
+    const size_t per_level = level == 0 ? 2 : ((size_t)1 << level);
+    const size_t outer = t / per_level;
+    if (outer >= (size_t)outerc) return;
+    const size_t j = level == 0 ? (t % per_level) : (per_level + t % per_level);
+    // rows are 2^window long except the last: 2^(scalar_size - (outerc-1)*window) (multiexp.tcc:815)
+    const size_t cur_len = (outer == (size_t)outerc - 1) ? ((size_t)1 << (scalar_size - (outerc - 1) * window)) : row_len;
+    if (j >= cur_len) return;
+    uint32_t* row = table + outer * row_len * XYZW;
+    Jac<E> p, go;
+    if (level == 0) {
+        if (j == 0) jac_set_inf(p); else load_jac(p, gouter + outer * XYZW);
+    } else {
+        load_jac(p, row + (j >> 1) * XYZW);
+        jac_dbl(p, p);
+        if (j & 1) {
+            load_jac(go, gouter + outer * XYZW);
+            jac_add(p, p, go);
+        }
+    }
+    store_jac(row + j * XYZW, p);
+}
+
+__global__ void __launch_bounds__(TPB) k_fb_exp(const uint32_t* __restrict__ table, const uint32_t* __restrict__ scalars,
+                                                size_t n, int mont, const uint32_t* __restrict__ coeff, int scalar_size,
+                                                int window, int form, uint32_t* __restrict__ out) {
+    const size_t i = gtid();
+    if (i >= n) return;
+    Fp<FR> x;
+    fp_load(x, scalars + i * FRW);
+    if (coeff) {   // coeff * v[i] (batch_exp_with_coeff, multiexp.tcc:937)
+        Fp<FR> cf;
+        fp_load(cf, coeff);
+        if (!mont) {
+            fp_to_mont(x, x);
+            fp_to_mont(cf, cf);
+        }
+        fp_mul(x, x, cf);
+        fp_from_mont(x, x);
+    } else if (mont) {
+        fp_from_mont(x, x);
+    }
+    const int outerc = (scalar_size + window - 1) / window;
+    const size_t row_len = (size_t)1 << window;
+    const uint32_t wmask = (1u << window) - 1u;
+    Jac<E> res, e;
+    jac_set_inf(res);   // powers_of_g[0][0] = zero
+    uint64_t buf = 0;
+    int nbits = 0, outer = 0;
+#pragma unroll
+    for (int j = 0; j < FRW; ++j) {
+        buf |= (uint64_t)x.v[j] << nbits;
+        nbits += 32;
+        while (nbits >= window && outer < outerc) {
+            const uint32_t inner = (uint32_t)buf & wmask;
+            buf >>= window;
+            nbits -= window;
+            if (inner) {
+                load_jac(e, table + ((size_t)outer * row_len + inner) * XYZW);
+                jac_add(res, res, e);
+            }
+            ++outer;
+        }
+    }
+    while (outer < outerc) {
+        const uint32_t inner = (uint32_t)buf & wmask;
+        buf >>= window;
+        if (inner) {
+            load_jac(e, table + ((size_t)outer * row_len + inner) * XYZW);
+            jac_add(res, res, e);
+        }
+        ++outer;
+    }
+    store_out(out + i * XYZW, res, form);
+}
+
 // -------------------------------------------------------------- FFI codecs
 // libff's FFI wire format (ffi/ffi_serialization.hpp:12-16, .tcc:19-187): every prime-field
 // component is a big-endian plain (non-Montgomery) integer padded to the in-memory bigint
@@ -1065,6 +1163,21 @@ void l_ffi_decode_scalars(hipStream_t st, const uint32_t* src, size_t n, uint32_
 void l_ffi_encode_point(hipStream_t st, const uint32_t* src_xyz, uint32_t* dst) {
     hipLaunchKernelGGL(k_ffi_encode_point, dim3(1), dim3(64), 0, st, src_xyz, dst);
 }
+// table: outerc * 2^window points, gouter: outerc points
+void l_fixed_base_exp(hipStream_t st, const uint32_t* g_xyz, int scalar_size, int window, const uint32_t* scalars, size_t n,
+                      int mont, const uint32_t* coeff, int form, uint32_t* gouter, uint32_t* table, uint32_t* out) {
+    const int outerc = (scalar_size + window - 1) / window;
+    hipLaunchKernelGGL(k_fb_gouter, dim3(1), dim3(64), 0, st, g_xyz, outerc, window, gouter);
+    for (int level = 0; level < window; ++level) {
+        const size_t per_level = level == 0 ? 2 : ((size_t)1 << level);
+        hipLaunchKernelGGL(k_fb_table_level, dim3(blocks_for((size_t)outerc * per_level)), dim3(TPB), 0, st, gouter, outerc,
+                           window, scalar_size, level, table);
+    }
+    if (n) {
+        hipLaunchKernelGGL(k_fb_exp, dim3(blocks_for(n)), dim3(TPB), 0, st, table, scalars, n, mont, coeff, scalar_size,
+                           window, form, out);
+    }
+}
 void l_field_op(hipStream_t st, int op, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t n) {
     if (!n) return;
     hipLaunchKernelGGL(k_field_op, dim3(blocks_for(n)), dim3(TPB), 0, st, op, a, b, out, n);
@@ -1101,7 +1214,7 @@ void l_madd_bench(hipStream_t st, const uint32_t* pts, uint32_t* out, size_t nth
 const group_vtable g_vt = {
     GP::CURVE, GP::GROUP, FRW, EW, FR::BITS, GP::LIBFF_PROJECTIVE ? 1 : 0, FR::R,
     l_import_bases, l_count, l_scatter, l_sort, l_accumulate, l_reduce_segments, l_sum_butterfly, l_horner, l_sum_points,
-    l_gen_bases_seq, l_export_affine, l_ffi_decode_points, l_ffi_decode_scalars, l_ffi_encode_point, l_field_op, l_group_op, l_digits, l_mul_bench, l_madd_bench,
+    l_gen_bases_seq, l_export_affine, l_ffi_decode_points, l_ffi_decode_scalars, l_ffi_encode_point, l_fixed_base_exp, l_field_op, l_group_op, l_digits, l_mul_bench, l_madd_bench,
 };
 
 }  // namespace

@@ -42,7 +42,7 @@ EXPORTED_SYMBOLS = [
     "amdmsm_device_count", "amdmsm_ctx_create", "amdmsm_ctx_destroy", "amdmsm_strerror",
     "amdmsm_last_error", "amdmsm_sizes", "amdmsm_plan", "amdmsm_pippenger_optimal_c",
     "amdmsm_bdlo12_signed_optimal_c", "amdmsm_multi_exp", "amdmsm_multi_exp_filter_one_zero",
-    "amdmsm_batch_to_special", "amdmsm_import_bases_device", "amdmsm_export_affine_device",
+    "amdmsm_batch_to_special", "amdmsm_batch_exp", "amdmsm_import_bases_device", "amdmsm_export_affine_device",
     "amdmsm_msm_device", "amdmsm_sum_points_device", "amdmsm_gen_bases_seq_device",
     "amdmsm_set_timing", "amdmsm_get_timings", "amdmsm_set_pipeline_depth", "amdmsm_last_slot",
     "amdmsm_get_slot_timings", "amdmsm_field_op_device", "amdmsm_group_op_device",
@@ -218,6 +218,22 @@ class Engine:
                                               ctypes.c_size_t(elems.shape[0]))
         self._check(rc, "amdmsm_batch_to_special")
         return elems
+
+    def batch_exp(self, curve, group, scalar_size, window, g, v, coeff=None, scalars_plain=False):
+        """libff::batch_exp / batch_exp_with_coeff (multiexp.tcc:874-947) for the table that
+        get_window_table(scalar_size, window, g) would build: res[i] = (coeff *) v[i] * g."""
+        g = np.ascontiguousarray(g, dtype=np.uint64)
+        v = np.ascontiguousarray(v, dtype=np.uint64)
+        s = sizes(curve, group)
+        n = v.shape[0]
+        out = np.zeros((n, s["g_bytes"] // 8), dtype=np.uint64)
+        cf = np.ascontiguousarray(coeff, dtype=np.uint64) if coeff is not None else None
+        rc = self.lib.amdmsm_batch_exp(self.h, curve, group, ctypes.c_size_t(scalar_size), ctypes.c_size_t(window),
+                                       _np_ptr(g), _np_ptr(v) if n else None, ctypes.c_size_t(n),
+                                       _np_ptr(cf) if cf is not None else None, int(scalars_plain),
+                                       _np_ptr(out) if n else None)
+        self._check(rc, "amdmsm_batch_exp")
+        return out
 
     def sum_points(self, curve, group, points_jacobian, out_form=OUT_AFFINE):
         """Sum of engine-Jacobian partial results (the serial tail of multiexp.tcc:681-687)."""

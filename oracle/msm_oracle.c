@@ -1188,6 +1188,59 @@ int orc_batch_to_special(int curve, int group, size_t n, uint64_t *elems)
     return 0;
 }
 
+/* ------------------------------------------------- fixed-base exponentiation */
+/* get_window_table (multiexp.tcc:809-846) + windowed_exp (:848-872) + batch_exp (:874-912) /
+ * batch_exp_with_coeff (:914-947).  out: n (X, Y, Z) records, same coordinates as the reference
+ * produces (same sequence of operator+ calls). */
+int orc_batch_exp(int curve, int group, size_t scalar_size, size_t window, const uint64_t *g_in, size_t n,
+                  const uint64_t *scalars, const uint64_t *coeff, uint64_t *out)
+{
+    const orc_group *g = find_group(curve, group);
+    if (!g) return -2;
+    ctx_t c = mkctx(g);
+    const int gl = GLIMBS(&c), rn = g->fr->n;
+    const size_t in_window = (size_t)1 << window;
+    const size_t outerc = (scalar_size + window - 1) / window;
+    const size_t last_in_window = (size_t)1 << (scalar_size - (outerc - 1) * window);
+    uint64_t *table = (uint64_t *)malloc(outerc * in_window * (size_t)gl * 8);
+    uint64_t gouter[MAXG], ginner[MAXG];
+    g_cpy(&c, gouter, g_in);
+    for (size_t outer = 0; outer < outerc; ++outer) {
+        g_zero(&c, ginner);
+        const size_t cur = (outer == outerc - 1) ? last_in_window : in_window;
+        for (size_t inner = 0; inner < in_window; ++inner) {
+            uint64_t *e = table + (outer * in_window + inner) * gl;
+            if (inner < cur) {
+                g_cpy(&c, e, ginner);
+                g_add(&c, ginner, ginner, gouter);
+            } else {
+                g_zero(&c, e);
+            }
+        }
+        for (size_t i = 0; i < window; ++i) g_add(&c, gouter, gouter, gouter);
+    }
+    for (size_t i = 0; i < n; ++i) {
+        uint64_t k[MAXN], t[MAXN], res[MAXG];
+        if (coeff) {
+            fp_mul(g->fr, t, coeff, scalars + i * rn);
+            fp_from_mont(g->fr, k, t);
+        } else {
+            fp_from_mont(g->fr, k, scalars + i * rn);
+        }
+        g_cpy(&c, res, table); /* powers_of_g[0][0] */
+        for (size_t outer = 0; outer < outerc; ++outer) {
+            size_t inner = 0;
+            for (size_t b = 0; b < window; ++b) {
+                if (bi_test_bit(k, rn, outer * window + b)) inner |= (size_t)1 << b;
+            }
+            g_add(&c, res, res, table + (outer * in_window + inner) * gl);
+        }
+        g_cpy(&c, out + i * gl, res);
+    }
+    free(table);
+    return 0;
+}
+
 /* ------------------------------------------------------------ FFI codecs */
 /* object_write_to_buffer / field_serializer, ffi_serialization.tcc:19-136:
  * big-endian plain bigint, extension coefficients highest-order first. */

@@ -61,6 +61,11 @@ int orc_group_consts(int curve, int group, uint64_t *one, uint64_t *zero);
 /* batch_to_special (multiexp.tcc:949-974) in place on n elements */
 int orc_batch_to_special(int curve, int group, size_t n, uint64_t *elems);
 
+/* batch_exp / batch_exp_with_coeff over get_window_table(scalar_size, window, g)
+ * (multiexp.tcc:809-947); coeff may be NULL; out: n (X, Y, Z) records */
+int orc_batch_exp(int curve, int group, size_t scalar_size, size_t window, const uint64_t *g, size_t n,
+                  const uint64_t *scalars, const uint64_t *coeff, uint64_t *out);
+
 size_t orc_log2(size_t n);
 size_t orc_pippenger_optimal_c(size_t n);
 size_t orc_bdlo12_signed_optimal_c(size_t n);

@@ -164,6 +164,17 @@ def batch_to_special(curve, group, elems):
     return elems
 
 
+def batch_exp(curve, group, scalar_size, window, g, v, coeff=None):
+    s = sizes(curve, group)
+    g, v = _u64(g), _u64(v)
+    n = v.shape[0]
+    out = np.zeros((n, s["g_bytes"] // 8), dtype=np.uint64)
+    cf = _u64(coeff) if coeff is not None else None
+    assert lib().orc_batch_exp(curve, group, ctypes.c_size_t(scalar_size), ctypes.c_size_t(window), _p(g),
+                               ctypes.c_size_t(n), _p(v), _p(cf), _p(out)) == 0
+    return out
+
+
 def bdlo12_signed_optimal_c(n):
     return int(lib().orc_bdlo12_signed_optimal_c(ctypes.c_size_t(n)))
 

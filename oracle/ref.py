@@ -170,6 +170,18 @@ def fr_consts(curve):
     return mod, r2, inv.value
 
 
+def batch_exp(curve, group, scalar_size, window, g, v, coeff=None):
+    s = sizes(curve, group)
+    g = np.ascontiguousarray(g, dtype=np.uint64)
+    v = np.ascontiguousarray(v, dtype=np.uint64)
+    n = v.shape[0]
+    out = np.zeros((n, s["g_bytes"] // 8), dtype=np.uint64)
+    cf = np.ascontiguousarray(coeff, dtype=np.uint64) if coeff is not None else None
+    assert lib().ref_batch_exp(curve, group, ctypes.c_size_t(scalar_size), ctypes.c_size_t(window), _p(g),
+                               ctypes.c_size_t(n), _p(v), _p(cf), _p(out)) == 0
+    return out
+
+
 def bdlo12_signed_optimal_c(n):
     return int(lib().ref_bdlo12_signed_optimal_c(ctypes.c_size_t(n)))
 

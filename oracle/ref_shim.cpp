@@ -251,6 +251,27 @@ template<typename G, typename Fr> struct ops {
         return field_get_digit(bi, c, idx);
     }
 
+    // get_window_table + batch_exp / batch_exp_with_coeff (multiexp.tcc:809-947)
+    static int batch_exp_c(
+        size_t scalar_size, size_t window, const void *g_in, size_t n, const void *scalars, const void *coeff, void *out)
+    {
+        G g;
+        memcpy((void *)&g, g_in, sizeof(G));
+        std::vector<Fr> v(n);
+        memcpy((void *)v.data(), scalars, n * sizeof(Fr));
+        const window_table<G> table = get_window_table<G>(scalar_size, window, g);
+        std::vector<G> res;
+        if (coeff) {
+            Fr cf;
+            memcpy((void *)&cf, coeff, sizeof(Fr));
+            res = batch_exp_with_coeff<G, Fr>(scalar_size, window, table, cf, v);
+        } else {
+            res = batch_exp<G, Fr>(scalar_size, window, table, v);
+        }
+        memcpy(out, (const void *)res.data(), n * sizeof(G));
+        return 0;
+    }
+
     // constants: Fr modulus, Fr R^2, Fr inv | Fq-component modulus, R^2, inv |
     // G::one() | G::zero()
     static void group_consts(void *one, void *zero)
@@ -433,6 +454,15 @@ int ref_fr_consts(int curve, void *mod, void *r2, uint64_t *inv)
 {
     DISPATCH(curve, GROUP_G1, O::fr_consts(mod, r2, inv));
     return 0;
+}
+
+int ref_batch_exp(
+    int curve, int group, size_t scalar_size, size_t window, const void *g, size_t n, const void *scalars,
+    const void *coeff, void *out)
+{
+    int rc = 0;
+    DISPATCH(curve, group, rc = O::batch_exp_c(scalar_size, window, g, n, scalars, coeff, out));
+    return rc;
 }
 
 int ref_coord_consts(int curve, int group, int which, void *out)

@@ -16,6 +16,7 @@
 
 #include <libff_amd/multiexp.hpp>
 
+#include <algorithm>
 #include <cstdio>
 #include <vector>
 
@@ -50,7 +51,21 @@ template<typename G, typename Fr> void check_group(const char *name, const std::
             bases.cbegin(), bases.cend(), scalars.cbegin(), scalars.cend(), 2);
         const G r4 = multi_exp_filter_one_zero<G, Fr, multi_exp_method_BDLO12_signed, multi_exp_base_form_special>(
             special.cbegin(), special.cend(), scalars.cbegin(), scalars.cend(), 1);
-        const bool ok = (expect == r1) && (expect == r2) && (expect == r3) && (expect == r4);
+        bool ok = (expect == r1) && (expect == r2) && (expect == r3) && (expect == r4);
+        // fixed-base batch exponentiation: deduced call -> device overload; explicit template
+        // arguments -> libff's CPU body (multiexp.tcc:874-947)
+        if (n >= 5) {
+            const size_t window = 5;
+            const window_table<G> table = get_window_table<G>(Fr::size_in_bits(), window, bases[1]);
+            const std::vector<Fr> v(scalars.begin(), scalars.begin() + std::min<size_t>(n, 200));
+            const std::vector<G> dev = batch_exp(Fr::size_in_bits(), window, table, v);
+            const std::vector<G> cpu = batch_exp<G, Fr>(Fr::size_in_bits(), window, table, v);
+            const std::vector<G> devc = batch_exp_with_coeff(Fr::size_in_bits(), window, table, scalars[4], v);
+            const std::vector<G> cpuc = batch_exp_with_coeff<G, Fr>(Fr::size_in_bits(), window, table, scalars[4], v);
+            for (size_t i = 0; i < v.size(); ++i) {
+                ok = ok && (dev[i] == cpu[i]) && (devc[i] == cpuc[i]);
+            }
+        }
         printf("%-14s n=%-6zu %s\n", name, n, ok ? "ok" : "MISMATCH");
         if (!ok) {
             ++failures;

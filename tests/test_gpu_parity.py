@@ -324,3 +324,32 @@ def test_ffi_multiexp(engine, port, name, curve, sym):
     # empty input -> zero = (0, 1)
     assert call(np.zeros(0, dtype=np.uint8), np.zeros(0, dtype=np.uint8), out)
     assert (out == zero_enc).all()
+
+
+@pytest.mark.parametrize("name,curve,group", GROUPS)
+def test_batch_exp_fixed_base(engine, port, name, curve, group):
+    """Fixed-base batch exponentiation: get_window_table + batch_exp /
+    batch_exp_with_coeff (multiexp.tcc:809-947) against the golden vectors and the oracle."""
+    g = golden()
+    bits = libff_amd.sizes(curve, group)["fr_bits"]
+    gb, v = g[f"{name}/bexp_g"], g[f"{name}/bexp_v"]
+
+    def affine(rows):
+        return engine.group_op(curve, group, 2, rows, None, OUT_AFFINE) if False else \
+            np.stack([port.group_op(curve, group, 4, x) for x in rows])
+
+    for w in (3, 5):
+        got = engine.batch_exp(curve, group, bits, w, gb, v)
+        assert (affine(got) == g[f"{name}/bexp_w{w}_affine"]).all(), w
+    got = engine.batch_exp(curve, group, bits, 4, gb, v, coeff=v[5])
+    assert (affine(got) == g[f"{name}/bexp_coeff_w4_affine"]).all()
+    # larger batch, wide window, against the oracle's scalar_mul (curve_utils.tcc:14-32)
+    n = 600 if curve != 2 else 150
+    sc = port.scalars_sha512(curve, 77, n)
+    sc[1] = 0
+    one = port.group_consts(curve, group)[0]
+    got = engine.batch_exp(curve, group, bits, 11, one, sc)
+    for i in list(range(0, n, 37)) + [1]:
+        want = port.group_op(curve, group, 4, port.scalar_mul(curve, group, one, sc[i]))
+        assert (port.group_op(curve, group, 4, got[i]) == want).all(), i
+    assert engine.batch_exp(curve, group, bits, 7, one, sc[:0]).shape[0] == 0

@@ -174,3 +174,15 @@ def test_ffi_codec_roundtrip(port, name, curve, group):
     assert port.ffi_group_read(curve, group, allff) is None
     sc = g[f"{name}/sha_scalars_0_16"][3]
     assert (port.ffi_fr_read(curve, port.ffi_fr_write(curve, sc)) == sc).all()
+
+
+@pytest.mark.parametrize("name,curve,group", GROUPS)
+def test_batch_exp(port, name, curve, group):
+    """get_window_table + batch_exp / batch_exp_with_coeff (multiexp.tcc:809-947)."""
+    g = golden()
+    bits = port.sizes(curve, group)["fr_bits"]
+    gb, v = g[f"{name}/bexp_g"], g[f"{name}/bexp_v"]
+    for w in (3, 5):
+        assert (port.batch_exp(curve, group, bits, w, gb, v) == g[f"{name}/bexp_w{w}"]).all()
+    r = port.batch_exp(curve, group, bits, 4, gb, v, coeff=v[5])
+    assert (np.stack([port.group_op(curve, group, 4, x) for x in r]) == g[f"{name}/bexp_coeff_w4_affine"]).all()
