@@ -34,14 +34,15 @@ import torch.distributed as dist  # noqa: E402
 import libff_amd  # noqa: E402
 from libff_amd.distributed import ShardedMsm  # noqa: E402
 
-CURVES = {"alt_bn128": 0, "bls12_377": 1, "bw6_761": 2}
+CURVES = {"alt_bn128": 0, "bls12_377": 1, "bw6_761": 2, "bls12_381": 3}
 # one scalar + one affine base per scalar-mul
-ALGO_BYTES = {(0, 1): 96, (1, 1): 128, (1, 2): 224, (2, 1): 240, (0, 2): 160, (2, 2): 240}
+ALGO_BYTES = {(0, 1): 96, (1, 1): 128, (1, 2): 224, (2, 1): 240, (0, 2): 160, (2, 2): 240, (3, 1): 128, (3, 2): 224}
 HBM_PEAK_GBS = 8000.0
 FR_MODULUS = {
     0: 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001,
     1: 0x12AB655E9A2CA55660B44D1E5C37B00159AA76FED00000010A11800000000001,
     2: 0x1AE3A4617C510EAC63B05C06CA1493B1A22D9F300F5138F1EF3622FBA094800170B5D44300000008508C00000000001,
+    3: 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001,
 }
 
 

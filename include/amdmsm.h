@@ -42,7 +42,12 @@
 extern "C" {
 #endif
 
-enum { AMDMSM_CURVE_ALT_BN128 = 0, AMDMSM_CURVE_BLS12_377 = 1, AMDMSM_CURVE_BW6_761 = 2 };
+enum {
+    AMDMSM_CURVE_ALT_BN128 = 0,
+    AMDMSM_CURVE_BLS12_377 = 1,
+    AMDMSM_CURVE_BW6_761 = 2,
+    AMDMSM_CURVE_BLS12_381 = 3
+};
 enum { AMDMSM_G1 = 1, AMDMSM_G2 = 2 };
 /* multi_exp_base_form, multiexp.hpp:45-51 */
 enum { AMDMSM_FORM_NORMAL = 0, AMDMSM_FORM_SPECIAL = 1 };

@@ -11,7 +11,7 @@
 // Method, BaseForm> (multiexp.tcc:205-212) whose BDLO12 / BDLO12_signed bodies are partial
 // specialisations generic in GroupT (multiexp.tcc:276-381, 507-633).  The specialisations
 // below fix GroupT/FieldT as well, are therefore more specialised, and are picked for
-//   alt_bn128_G1/G2, bls12_377_G1/G2, bw6_761_G1/G2
+//   alt_bn128_G1/G2, bls12_377_G1/G2, bls12_381_G1/G2, bw6_761_G1/G2
 // while every other (group, method) pair keeps the reference's CPU body.  multi_exp itself
 // (chunk split + serial sum, multiexp.tcc:643-688) and multi_exp_filter_one_zero (:690-757) are
 // the reference's own code and simply call into the engine per chunk.  Fixed-base
@@ -226,6 +226,7 @@ std::vector<GroupT> gpu_batch_exp(
 #ifdef LIBFF_AMD_ALL_CURVES
 #include <libff/algebra/curves/alt_bn128/alt_bn128_pp.hpp>
 #include <libff/algebra/curves/bls12_377/bls12_377_pp.hpp>
+#include <libff/algebra/curves/bls12_381/bls12_381_pp.hpp>
 #include <libff/algebra/curves/bw6_761/bw6_761_pp.hpp>
 #endif
 
@@ -236,6 +237,10 @@ LIBFF_AMD_ROUTE_GROUP(libff::alt_bn128_G2, libff::alt_bn128_Fr, AMDMSM_CURVE_ALT
 #ifdef BLS12_377_PP_HPP_
 LIBFF_AMD_ROUTE_GROUP(libff::bls12_377_G1, libff::bls12_377_Fr, AMDMSM_CURVE_BLS12_377, AMDMSM_G1)
 LIBFF_AMD_ROUTE_GROUP(libff::bls12_377_G2, libff::bls12_377_Fr, AMDMSM_CURVE_BLS12_377, AMDMSM_G2)
+#endif
+#ifdef BLS12_381_PP_HPP_
+LIBFF_AMD_ROUTE_GROUP(libff::bls12_381_G1, libff::bls12_381_Fr, AMDMSM_CURVE_BLS12_381, AMDMSM_G1)
+LIBFF_AMD_ROUTE_GROUP(libff::bls12_381_G2, libff::bls12_381_Fr, AMDMSM_CURVE_BLS12_381, AMDMSM_G2)
 #endif
 #ifdef BW6_761_PP_HPP_
 LIBFF_AMD_ROUTE_GROUP(libff::bw6_761_G1, libff::bw6_761_Fr, AMDMSM_CURVE_BW6_761, AMDMSM_G1)

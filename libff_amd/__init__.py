@@ -10,13 +10,13 @@ There is no CPU implementation in this package: importing is cheap, but every co
 entry raises if libamdmsm.so is missing or no GPU is visible.
 """
 from .engine import (  # noqa: F401
-    ALT_BN128, BLS12_377, BW6_761, G1, G2, OUT_AFFINE, OUT_JACOBIAN, OUT_LIBFF, AmdMsmError, Engine,
+    ALT_BN128, BLS12_377, BLS12_381, BW6_761, G1, G2, OUT_AFFINE, OUT_JACOBIAN, OUT_LIBFF, AmdMsmError, Engine,
     bdlo12_signed_optimal_c, load_library, multi_exp_base_form_normal, multi_exp_base_form_special,
     multi_exp_method_BDLO12, multi_exp_method_BDLO12_signed, multi_exp_method_bos_coster,
     multi_exp_method_naive, multi_exp_method_naive_plain, pippenger_optimal_c, plan, sizes)
 
 __all__ = [
-    "ALT_BN128", "BLS12_377", "BW6_761", "G1", "G2", "OUT_AFFINE", "OUT_JACOBIAN", "OUT_LIBFF",
+    "ALT_BN128", "BLS12_377", "BLS12_381", "BW6_761", "G1", "G2", "OUT_AFFINE", "OUT_JACOBIAN", "OUT_LIBFF",
     "AmdMsmError", "Engine", "bdlo12_signed_optimal_c", "load_library", "multi_exp_base_form_normal",
     "multi_exp_base_form_special", "multi_exp_method_BDLO12", "multi_exp_method_BDLO12_signed",
     "multi_exp_method_bos_coster", "multi_exp_method_naive", "multi_exp_method_naive_plain",

@@ -16,7 +16,8 @@ OBJ = os.path.join(CSRC, "build")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 SO_PATH = os.path.join(HERE, "libamdmsm.so")
 
-GROUPS = ["alt_bn128_g1", "alt_bn128_g2", "bls12_377_g1", "bls12_377_g2", "bw6_761_g1", "bw6_761_g2"]
+GROUPS = ["alt_bn128_g1", "alt_bn128_g2", "bls12_377_g1", "bls12_377_g2", "bw6_761_g1", "bw6_761_g2",
+          "bls12_381_g1", "bls12_381_g2"]
 # per-group code-generation policy (see fp.cuh Fp<P, INL> and msm_group.hip):
 #   AMDMSM_HOT_INLINE  inline the Montgomery product inside the bucket-accumulation loop
 #   AMDMSM_BENCH_BOTH  also build the inline variants of the throughput probes

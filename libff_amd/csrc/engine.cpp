@@ -52,6 +52,7 @@ using vt_getter = const group_vtable *(*)();
 const group_vtable *find_vt(int curve, int group) {
     static const vt_getter getters[] = {
         vt_alt_bn128_g1, vt_alt_bn128_g2, vt_bls12_377_g1, vt_bls12_377_g2, vt_bw6_761_g1, vt_bw6_761_g2,
+        vt_bls12_381_g1, vt_bls12_381_g2,
     };
     for (vt_getter g : getters) {
         if (!g) continue;

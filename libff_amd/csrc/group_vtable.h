@@ -92,5 +92,7 @@ const group_vtable* vt_bls12_377_g1() __attribute__((weak));
 const group_vtable* vt_bls12_377_g2() __attribute__((weak));
 const group_vtable* vt_bw6_761_g1() __attribute__((weak));
 const group_vtable* vt_bw6_761_g2() __attribute__((weak));
+const group_vtable* vt_bls12_381_g1() __attribute__((weak));
+const group_vtable* vt_bls12_381_g2() __attribute__((weak));
 
 }  // namespace amdmsm

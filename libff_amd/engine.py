@@ -20,9 +20,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(HERE, "libamdmsm.so")
 
 # curve / group ids (include/amdmsm.h)
-ALT_BN128, BLS12_377, BW6_761 = 0, 1, 2
+ALT_BN128, BLS12_377, BW6_761, BLS12_381 = 0, 1, 2, 3
 G1, G2 = 1, 2
-CURVE_NAMES = {ALT_BN128: "alt_bn128", BLS12_377: "bls12_377", BW6_761: "bw6_761"}
+CURVE_NAMES = {ALT_BN128: "alt_bn128", BLS12_377: "bls12_377", BW6_761: "bw6_761", BLS12_381: "bls12_381"}
 
 # libff::multi_exp_method, multiexp.hpp:21-43
 multi_exp_method_naive = 0

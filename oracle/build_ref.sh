@@ -29,6 +29,7 @@ SRCS=(
     "$REF"/libff/algebra/curves/alt_bn128/*.cpp
     "$REF"/libff/algebra/curves/bls12_377/*.cpp
     "$REF"/libff/algebra/curves/bw6_761/*.cpp
+    "$REF"/libff/algebra/curves/bls12_381/*.cpp
     "$REF"/libff/common/profiling.cpp
     "$REF"/libff/common/utils.cpp
     "$REF"/libff/common/double.cpp

@@ -13,7 +13,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(HERE, "libmsm_oracle.so")
 
-ALT_BN128, BLS12_377, BW6_761 = 0, 1, 2
+ALT_BN128, BLS12_377, BW6_761, BLS12_381 = 0, 1, 2, 3
 G1, G2 = 1, 2
 NAIVE, NAIVE_PLAIN, BOS_COSTER, BDLO12, BDLO12_SIGNED = 0, 1, 2, 3, 4
 FORM_NORMAL, FORM_SPECIAL = 0, 1

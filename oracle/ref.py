@@ -18,7 +18,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(HERE, "_ref", "libff_ref.so")
 
-ALT_BN128, BLS12_377, BW6_761 = 0, 1, 2
+ALT_BN128, BLS12_377, BW6_761, BLS12_381 = 0, 1, 2, 3
 G1, G2 = 1, 2
 # libff::multi_exp_method (multiexp.hpp:21-43)
 NAIVE, NAIVE_PLAIN, BOS_COSTER, BDLO12, BDLO12_SIGNED = 0, 1, 2, 3, 4

@@ -20,6 +20,7 @@
 
 #include <libff/algebra/curves/alt_bn128/alt_bn128_pp.hpp>
 #include <libff/algebra/curves/bls12_377/bls12_377_pp.hpp>
+#include <libff/algebra/curves/bls12_381/bls12_381_pp.hpp>
 #include <libff/algebra/curves/bw6_761/bw6_761_pp.hpp>
 #include <libff/algebra/fields/field_utils.hpp>
 #include <libff/algebra/scalar_multiplication/multiexp.hpp>
@@ -35,7 +36,7 @@ using namespace libff;
 namespace
 {
 
-enum { RC_ALT_BN128 = 0, RC_BLS12_377 = 1, RC_BW6_761 = 2 };
+enum { RC_ALT_BN128 = 0, RC_BLS12_377 = 1, RC_BW6_761 = 2, RC_BLS12_381 = 3 };
 enum { GROUP_G1 = 1, GROUP_G2 = 2 };
 
 bool g_init = false;
@@ -315,6 +316,8 @@ using bls_g1 = ops<bls12_377_G1, bls12_377_Fr>;
 using bls_g2 = ops<bls12_377_G2, bls12_377_Fr>;
 using bw_g1 = ops<bw6_761_G1, bw6_761_Fr>;
 using bw_g2 = ops<bw6_761_G2, bw6_761_Fr>;
+using b381_g1 = ops<bls12_381_G1, bls12_381_Fr>;
+using b381_g2 = ops<bls12_381_G2, bls12_381_Fr>;
 
 #define DISPATCH(curve, group, EXPR)                                           \
     do {                                                                       \
@@ -325,6 +328,8 @@ using bw_g2 = ops<bw6_761_G2, bw6_761_Fr>;
         else if (curve == RC_BLS12_377 && group == GROUP_G2) { using O = bls_g2; EXPR; } \
         else if (curve == RC_BW6_761 && group == GROUP_G1) { using O = bw_g1; EXPR; }    \
         else if (curve == RC_BW6_761 && group == GROUP_G2) { using O = bw_g2; EXPR; }    \
+        else if (curve == RC_BLS12_381 && group == GROUP_G1) { using O = b381_g1; EXPR; } \
+        else if (curve == RC_BLS12_381 && group == GROUP_G2) { using O = b381_g2; EXPR; } \
         else return -2;                                                        \
     } while (0)
 
@@ -341,6 +346,7 @@ int ref_init(void)
         alt_bn128_pp::init_public_params();
         bls12_377_pp::init_public_params();
         bw6_761_pp::init_public_params();
+        bls12_381_pp::init_public_params();
         g_init = true;
     }
     return 0;

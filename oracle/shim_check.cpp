@@ -10,6 +10,7 @@
 // tests/test_gpu_shim.py.
 #include <libff/algebra/curves/alt_bn128/alt_bn128_pp.hpp>
 #include <libff/algebra/curves/bls12_377/bls12_377_pp.hpp>
+#include <libff/algebra/curves/bls12_381/bls12_381_pp.hpp>
 #include <libff/algebra/curves/bw6_761/bw6_761_pp.hpp>
 #include <libff/common/profiling.hpp>
 #include <libff/common/rng.hpp>
@@ -80,12 +81,15 @@ int main()
     alt_bn128_pp::init_public_params();
     bls12_377_pp::init_public_params();
     bw6_761_pp::init_public_params();
+    bls12_381_pp::init_public_params();
     check_group<alt_bn128_G1, alt_bn128_Fr>("alt_bn128_G1", {1, 2, 5, 257, 4096});
     check_group<alt_bn128_G2, alt_bn128_Fr>("alt_bn128_G2", {1, 5, 600});
     check_group<bls12_377_G1, bls12_377_Fr>("bls12_377_G1", {1, 5, 1500});
     check_group<bls12_377_G2, bls12_377_Fr>("bls12_377_G2", {1, 5, 300});
     check_group<bw6_761_G1, bw6_761_Fr>("bw6_761_G1", {1, 5, 300});
     check_group<bw6_761_G2, bw6_761_Fr>("bw6_761_G2", {1, 5, 300});
+    check_group<bls12_381_G1, bls12_381_Fr>("bls12_381_G1", {1, 5, 1000});
+    check_group<bls12_381_G2, bls12_381_Fr>("bls12_381_G2", {1, 5, 300});
     printf(failures ? "SHIM CHECK FAILED (%d)\n" : "SHIM CHECK PASSED\n", failures);
     return failures ? 1 : 0;
 }

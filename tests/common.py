@@ -11,6 +11,7 @@ LITERAL_JSON = os.path.join(HERE, "golden", "literal.json")
 GROUPS = [
     ("alt_bn128_g1", 0, 1), ("alt_bn128_g2", 0, 2), ("bls12_377_g1", 1, 1),
     ("bls12_377_g2", 1, 2), ("bw6_761_g1", 2, 1), ("bw6_761_g2", 2, 2),
+    ("bls12_381_g1", 3, 1), ("bls12_381_g2", 3, 2),
 ]
 GROUP_IDS = [g[0] for g in GROUPS]
 MSM_SIZES = [1, 2, 3, 4, 5, 256, 257]

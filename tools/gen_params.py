@@ -81,6 +81,28 @@ CURVES = {
             b=[4],
         ),
     ),
+    "bls12_381": dict(
+        id=3,
+        r=0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001,
+        q=0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB,
+        coords="jacobian",
+        g1=dict(
+            deg=1,
+            x=[0x17F1D3A73197D7942695638C4FA9AC0FC3688C4F9774B905A14E3A3F171BAC586C55E83FF97A1AEFFB3AF00ADB22C6BB],
+            y=[0x08B3F481E3AAA0F1A09E30ED741D8AE4FCF5E095D5D00AF600DB18CB2C04B3EDD03CC744A2888AE40CAA232946C5E7E1],
+            b=[4],
+            subgroup="order",   # bls12_381_g1.cpp:335-338
+        ),
+        g2=dict(
+            deg=2,
+            nr=-1,
+            x=[0x024AA2B2F08F0A91260805272DC51051C6E47AD4FA403B02B4510B647AE3D1770BAC0326A805BBEFD48056C8C121BDB8,
+               0x13E02B6052719F607DACD3A088274F65596BD0D09920B61AB5DA61BBDC7F5049334CF11213945D57E5AC7D055D042B7E],
+            y=[0x0CE5D527727D6E118CC9CDC6DA2E351AADFD9BAA8CBDD3A76D429A695160D12C923AC9CC3BACA289E193548608B82801,
+               0x0606C4A02EA734CC32ACD2B02BC28B99CB3E287E85A763AF267492AB572E99AB3F370D275CEC1DA1AAA9075FF05F79BE],
+            b=[4, 4],
+        ),
+    ),
 }
 
 
@@ -129,7 +151,7 @@ def emit_device_header():
     w("")
     w("namespace amdmsm {")
     w("")
-    w("enum curve_id : int { CURVE_ALT_BN128 = 0, CURVE_BLS12_377 = 1, CURVE_BW6_761 = 2 };")
+    w("enum curve_id : int { CURVE_ALT_BN128 = 0, CURVE_BLS12_377 = 1, CURVE_BW6_761 = 2, CURVE_BLS12_381 = 3 };")
     w("enum group_id : int { GROUP_G1 = 1, GROUP_G2 = 2 };")
     w("")
     done_fields = {}
