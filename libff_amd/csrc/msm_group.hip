@@ -732,14 +732,22 @@ __global__ void k_sum_points(const uint32_t* __restrict__ pts, int k, int form, 
 }
 
 // ------------------------------------------------------------ base import
+// libff (X, Y, Z) records -> compact affine.  Special form: copy.  Normal form: one lane takes
+// IMPORT_K consecutive points and shares a single field inversion among them (Montgomery's
+// trick, as batch_to_special / batch_invert do on the host: multiexp.tcc:949-974,
+// field_utils.tcc:419-439); prefix products are parked in the output slots between the two
+// passes.  Lanes whose points all have Z == 1 already (the usual case: default BaseForm on an
+// affine proving key) skip the inversion.
+constexpr int IMPORT_K = 32;
+
 __global__ void __launch_bounds__(TPB) k_import_bases(const uint32_t* __restrict__ src, size_t stride_words,
                                                       int form_special, size_t n, uint32_t* __restrict__ dst) {
-    const size_t i = gtid();
-    if (i >= n) return;
-    const uint32_t* q = src + i * stride_words;
-    Aff<E> a;
     if (form_special) {
+        const size_t i = gtid();
+        if (i >= n) return;
+        const uint32_t* q = src + i * stride_words;
         // Z == 1 or the element is zero (is_special, alt_bn128_g1.cpp:86-89)
+        Aff<E> a;
         E z;
         el_load(a.x, q);
         el_load(a.y, q + EW);
@@ -748,12 +756,50 @@ __global__ void __launch_bounds__(TPB) k_import_bases(const uint32_t* __restrict
             el_zero(a.x);
             el_zero(a.y);
         }
-    } else {
-        Jac<E> p;
-        load_libff(p, q);
-        jac_to_aff(a, p);
+        store_aff(dst + i * AFFW, a);
+        return;
     }
-    store_aff(dst + i * AFFW, a);
+    const size_t i0 = gtid() * IMPORT_K;
+    if (i0 >= n) return;
+    const size_t i1 = (i0 + IMPORT_K < n) ? i0 + IMPORT_K : n;
+    E one, acc;
+    el_one(one);
+    acc = one;
+    bool trivial = true;
+    for (size_t i = i0; i < i1; ++i) {
+        Jac<E> p;
+        load_libff(p, src + i * stride_words);
+        if (jac_is_inf(p)) continue;
+        el_store(dst + i * AFFW, acc);   // prefix product of the Z's before this point
+        if (!el_eq(p.z, one)) {
+            trivial = false;
+            el_mul(acc, acc, p.z);
+        }
+    }
+    E inv = one;
+    if (!trivial) el_inv(inv, acc);
+    for (size_t i = i1; i-- > i0;) {
+        Jac<E> p;
+        load_libff(p, src + i * stride_words);
+        Aff<E> a;
+        if (jac_is_inf(p)) {
+            el_zero(a.x);
+            el_zero(a.y);
+        } else if (el_eq(p.z, one)) {
+            a.x = p.x;
+            a.y = p.y;
+        } else {
+            E pre, zi, z2;
+            el_load(pre, dst + i * AFFW);
+            el_mul(zi, inv, pre);      // Z_i^-1
+            el_mul(inv, inv, p.z);
+            el_sqr(z2, zi);
+            el_mul(a.x, p.x, z2);
+            el_mul(z2, z2, zi);
+            el_mul(a.y, p.y, z2);
+        }
+        store_aff(dst + i * AFFW, a);
+    }
 }
 
 __global__ void __launch_bounds__(TPB) k_export_affine(const uint32_t* __restrict__ src, size_t n,
@@ -1087,7 +1133,8 @@ inline unsigned blocks_for(size_t n, int tpb = TPB) { return (unsigned)((n + tpb
 
 void l_import_bases(hipStream_t st, const uint32_t* src, size_t stride_words, int form_special, size_t n, uint32_t* dst) {
     if (!n) return;
-    hipLaunchKernelGGL(k_import_bases, dim3(blocks_for(n)), dim3(TPB), 0, st, src, stride_words, form_special, n, dst);
+    const size_t lanes = form_special ? n : (n + IMPORT_K - 1) / IMPORT_K;
+    hipLaunchKernelGGL(k_import_bases, dim3(blocks_for(lanes)), dim3(TPB), 0, st, src, stride_words, form_special, n, dst);
 }
 void l_count(hipStream_t st, const uint32_t* scalars, size_t n, int mont, int c, int W, uint32_t* counts) {
     if (!n) return;

@@ -353,3 +353,23 @@ def test_batch_exp_fixed_base(engine, port, name, curve, group):
         want = port.group_op(curve, group, 4, port.scalar_mul(curve, group, one, sc[i]))
         assert (port.group_op(curve, group, 4, got[i]) == want).all(), i
     assert engine.batch_exp(curve, group, bits, 7, one, sc[:0]).shape[0] == 0
+
+
+@pytest.mark.parametrize("name,curve,group", GROUPS)
+def test_normal_form_bases_batched_inversion(engine, port, name, curve, group):
+    """multi_exp_base_form_normal with genuinely projective bases, affine ones and zeros mixed
+    (the import shares one inversion per 32 points) and batch_to_special (multiexp.tcc:949-974)."""
+    n = 150 if curve != 2 else 70
+    aff = port.bases_seq(curve, group, n, first=20)
+    zero = port.group_consts(curve, group)[1]
+    mixed = aff.copy()
+    for i in range(n):
+        if i % 3 == 0:      # 3*P_i in projective form (Z != 1)
+            mixed[i] = port.group_op(curve, group, 0, port.group_op(curve, group, 2, aff[i]), aff[i])
+        elif i % 11 == 5:
+            mixed[i] = zero
+    sc = port.scalars_sha512(curve, 321, n)
+    want = port.multi_exp(curve, group, mixed, sc, port.BDLO12_SIGNED, 0)
+    got = engine.multi_exp(curve, group, mixed, sc, base_form=multi_exp_base_form_normal)
+    assert (got == want).all()
+    assert (engine.batch_to_special(curve, group, mixed) == port.batch_to_special(curve, group, mixed)).all()
