@@ -12,6 +12,8 @@
  *                             multiexp.tcc:690-757
  *   amdmsm_batch_to_special   libff::batch_to_special<G>, multiexp.hpp:136-141,
  *                             multiexp.tcc:949-974
+ *   amdmsm_multi_exp_stream   libff::multi_exp_stream (bases streamed in the on-disk format),
+ *                             multiexp_stream.hpp:25-33, multiexp_stream.tcc:164-191
  *   amdmsm_batch_exp          libff::get_window_table + batch_exp / batch_exp_with_coeff,
  *                             multiexp.hpp:99-134, multiexp.tcc:809-947
  *   amdmsm_bdlo12_signed_optimal_c / amdmsm_pippenger_optimal_c
@@ -119,6 +121,21 @@ int amdmsm_multi_exp_filter_one_zero(amdmsm_ctx *ctx, int curve, int group,
 
 int amdmsm_batch_to_special(amdmsm_ctx *ctx, int curve, int group, void *elems_xyz,
                             size_t stride_bytes, size_t n);
+
+/* Streaming MSM: bases are pulled through `read` in libff's on-disk format -- binary,
+ * Montgomery form, uncompressed, i.e. consecutive group_write<encoding_binary, form_montgomery,
+ * compression_off> records (curve_serialization.tcc:78-101; what profile_multiexp.cpp:100-150
+ * writes) -- chunk by chunk, so they never need to be resident at once.  Replaces
+ * multi_exp_stream<form_montgomery, compression_off, G, Fr> (multiexp_stream.hpp:25-33,
+ * multiexp_stream.tcc:164-191).  `read` returns the number of bytes delivered (0 = end).
+ * chunk_points = 0 picks 2^20. */
+typedef size_t (*amdmsm_read_fn)(void *read_ctx, void *dst, size_t bytes);
+int amdmsm_multi_exp_stream(amdmsm_ctx *ctx, int curve, int group, amdmsm_read_fn read, void *read_ctx,
+                            const void *scalars, size_t n, size_t chunk_points, void *out_xyz,
+                            const amdmsm_opts *opts);
+int amdmsm_multi_exp_stream_file(amdmsm_ctx *ctx, int curve, int group, const char *path,
+                                 size_t offset_bytes, const void *scalars, size_t n,
+                                 size_t chunk_points, void *out_xyz, const amdmsm_opts *opts);
 
 /* Fixed-base batch exponentiation: out[i] = scalars[i] * g (or (coeff * scalars[i]) * g when
  * coeff != NULL), i < n, through a window table built on the device.  Replaces

@@ -643,6 +643,128 @@ int amdmsm_multi_exp_filter_one_zero(amdmsm_ctx *ctx, int curve, int group, cons
     return amdmsm_multi_exp(ctx, curve, group, bases_xyz, base_stride_bytes, base_form, scalars, n, out_xyz, opts);
 }
 
+// multi_exp_stream (multiexp_stream.hpp:25-33, multiexp_stream.tcc:164-191): the bases arrive
+// through a reader in libff's on-disk format and never have to be resident at once.  Chunks of
+// `chunk_points` records are read into pinned staging buffers, copied and decoded on the
+// device, and reduced to one partial point each on alternating streams / workspace slots, so
+// reading chunk k+1 overlaps the MSM of chunk k; the partials are summed at the end
+// (multiexp.tcc:681-687).
+int amdmsm_multi_exp_stream(amdmsm_ctx *ctx, int curve, int group, amdmsm_read_fn read, void *read_ctx,
+                            const void *scalars, size_t n, size_t chunk_points, void *out_xyz,
+                            const amdmsm_opts *opts) {
+    if (!ctx || !read || !out_xyz || (n && !scalars)) return AMDMSM_ERR_BAD_ARG;
+    const group_vtable *vt = find_vt(curve, group);
+    if (!vt) return fail(ctx, AMDMSM_ERR_UNSUPPORTED, "unknown curve/group");
+    const size_t xyz_bytes = (size_t)vt->el_words * 12, aff_bytes = (size_t)vt->el_words * 8;
+    const size_t fr_bytes = (size_t)vt->fr_words * 4;
+    if (chunk_points == 0) chunk_points = (size_t)1 << 20;
+    if (chunk_points > n && n) chunk_points = n;
+    const size_t nchunks = n ? (n + chunk_points - 1) / chunk_points : 0;
+    constexpr int NB = 2;
+    void *h_stage[NB] = {}, *d_raw[NB] = {}, *d_aff[NB] = {}, *d_sc[NB] = {};
+    void *d_partials = nullptr;
+    hipStream_t streams[NB] = {};
+    int rc = AMDMSM_OK;
+    std::string err;
+    int old_depth = 1;
+    {
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        old_depth = ctx->depth;
+    }
+    dev_guard guard(ctx->device);
+    auto cleanup = [&]() {
+        (void)hipDeviceSynchronize();
+        for (int b = 0; b < NB; ++b) {
+            if (h_stage[b]) (void)hipHostFree(h_stage[b]);
+            if (d_raw[b]) (void)hipFree(d_raw[b]);
+            if (d_aff[b]) (void)hipFree(d_aff[b]);
+            if (d_sc[b]) (void)hipFree(d_sc[b]);
+            if (streams[b]) (void)hipStreamDestroy(streams[b]);
+        }
+        if (d_partials) (void)hipFree(d_partials);
+        (void)amdmsm_set_pipeline_depth(ctx, old_depth);
+    };
+#define TRY_S(expr)                                                                   \
+    do {                                                                              \
+        hipError_t e_ = (expr);                                                       \
+        if (e_ != hipSuccess) {                                                       \
+            err = std::string(#expr) + ": " + hipGetErrorString(e_);                  \
+            cleanup();                                                                \
+            return fail(ctx, AMDMSM_ERR_HIP, err);                                    \
+        }                                                                             \
+    } while (0)
+    rc = amdmsm_set_pipeline_depth(ctx, NB);
+    if (rc) return rc;
+    TRY_S(hipMalloc(&d_partials, (nchunks + 1) * xyz_bytes));
+    for (int b = 0; b < NB && nchunks; ++b) {
+        TRY_S(hipHostMalloc(&h_stage[b], chunk_points * aff_bytes, hipHostMallocDefault));
+        TRY_S(hipMalloc(&d_raw[b], chunk_points * aff_bytes));
+        TRY_S(hipMalloc(&d_aff[b], chunk_points * aff_bytes));
+        TRY_S(hipMalloc(&d_sc[b], chunk_points * fr_bytes));
+        TRY_S(hipStreamCreateWithFlags(&streams[b], hipStreamNonBlocking));
+    }
+    amdmsm_opts o = {};
+    if (opts) o = *opts;
+    const int final_form = opts ? opts->out_form : AMDMSM_OUT_LIBFF;
+    o.out_form = AMDMSM_OUT_JACOBIAN;
+    for (size_t k = 0; k < nchunks; ++k) {
+        const int b = (int)(k % NB);
+        const size_t lo = k * chunk_points, cnt = std::min(chunk_points, n - lo);
+        TRY_S(hipStreamSynchronize(streams[b]));   // staging buffer b is free again
+        const size_t want = cnt * aff_bytes;
+        size_t got = 0;
+        while (got < want) {
+            const size_t r = read(read_ctx, (char *)h_stage[b] + got, want - got);
+            if (r == 0) break;
+            got += r;
+        }
+        if (got != want) {
+            cleanup();
+            return fail(ctx, AMDMSM_ERR_BAD_ARG, "base-element stream ended early");
+        }
+        TRY_S(hipMemcpyAsync(d_raw[b], h_stage[b], want, hipMemcpyHostToDevice, streams[b]));
+        TRY_S(hipMemcpyAsync(d_sc[b], (const char *)scalars + lo * fr_bytes, cnt * fr_bytes, hipMemcpyHostToDevice,
+                             streams[b]));
+        vt->disk_decode(streams[b], (const uint32_t *)d_raw[b], cnt, (uint32_t *)d_aff[b]);
+        o.stream = streams[b];
+        rc = amdmsm_msm_device(ctx, curve, group, d_aff[b], d_sc[b], cnt, (char *)d_partials + k * xyz_bytes, &o);
+        if (rc) {
+            cleanup();
+            return rc;
+        }
+    }
+    TRY_S(hipDeviceSynchronize());
+    {
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        vt->sum_points(ctx->stream, (const uint32_t *)d_partials, (int)nchunks, final_form,
+                       (uint32_t *)((char *)d_partials + nchunks * xyz_bytes));
+    }
+    TRY_S(hipMemcpyAsync(out_xyz, (char *)d_partials + nchunks * xyz_bytes, xyz_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    TRY_S(hipStreamSynchronize(ctx->stream));
+    cleanup();
+    return AMDMSM_OK;
+#undef TRY_S
+}
+
+namespace {
+size_t file_reader(void *fp, void *dst, size_t bytes) { return fread(dst, 1, bytes, (FILE *)fp); }
+}  // namespace
+
+int amdmsm_multi_exp_stream_file(amdmsm_ctx *ctx, int curve, int group, const char *path, size_t offset_bytes,
+                                 const void *scalars, size_t n, size_t chunk_points, void *out_xyz,
+                                 const amdmsm_opts *opts) {
+    if (!ctx || !path) return AMDMSM_ERR_BAD_ARG;
+    FILE *fp = fopen(path, "rb");
+    if (!fp) return fail(ctx, AMDMSM_ERR_BAD_ARG, std::string("cannot open ") + path);
+    if (offset_bytes && fseek(fp, (long)offset_bytes, SEEK_SET) != 0) {
+        fclose(fp);
+        return fail(ctx, AMDMSM_ERR_BAD_ARG, "seek failed");
+    }
+    const int rc = amdmsm_multi_exp_stream(ctx, curve, group, file_reader, fp, scalars, n, chunk_points, out_xyz, opts);
+    fclose(fp);
+    return rc;
+}
+
 int amdmsm_batch_exp(amdmsm_ctx *ctx, int curve, int group, size_t scalar_size, size_t window, const void *g_xyz,
                      const void *scalars, size_t n, const void *coeff, int scalars_plain, void *out_xyz) {
     GET_VT(ctx, curve, group);

@@ -64,6 +64,8 @@ struct group_vtable {
     void (*ffi_decode_scalars)(hipStream_t, const uint32_t* src_be, size_t n, uint32_t* dst_plain, uint32_t* status);
     void (*ffi_encode_point)(hipStream_t, const uint32_t* src_xyz_affine, uint32_t* dst_be);
 
+    // libff on-disk base records (binary, Montgomery, uncompressed) -> compact affine
+    void (*disk_decode)(hipStream_t, const uint32_t* src, size_t n, uint32_t* dst_affine);
     // fixed-base batch exponentiation: out[i] = (coeff *) scalars[i] * g via a window table
     // (get_window_table / windowed_exp / batch_exp[_with_coeff], multiexp.tcc:809-947);
     // gouter: outerc points, table: outerc * 2^window points, outerc = ceil(scalar_size / window)

@@ -59,6 +59,7 @@ constexpr int FRW = FR::N;            // words per scalar
 constexpr int TPB = 256;
 
 AMDMSM_DEV size_t gtid() { return (size_t)blockIdx.x * blockDim.x + threadIdx.x; }
+AMDMSM_DEV uint32_t bswap32(uint32_t v) { return __builtin_bswap32(v); }
 
 template <class T> AMDMSM_DEV void load_aff(Aff<T>& p, const uint32_t* q) {
     el_load(p.x, q);
@@ -830,6 +831,36 @@ __global__ void __launch_bounds__(TPB) k_gen_bases_seq(unsigned long long first,
     store_aff(dst + i * AFFW, a);
 }
 
+// ------------------------------------------------------------ on-disk bases
+// libff's binary, Montgomery, uncompressed group-element records (what multi_exp_stream reads,
+// multiexp_stream.tcc:19-49; writer group_element_codec<encoding_binary, Form, compression_off>,
+// curve_serialization.tcc:78-101): affine X || Y; every Fq component is the Montgomery residue
+// with its bytes reversed (big-endian; field_serialization.tcc:197-223), extension
+// coefficients in ascending order c0, c1 (field_serialization.tcc:124-146); zero = (0, one).
+template <bool I>
+AMDMSM_DEV void load_be_raw(Fp<FQ, I>& r, const uint32_t* __restrict__ src) {
+#pragma unroll
+    for (int j = 0; j < FQ::N; ++j) r.v[j] = bswap32(src[FQ::N - 1 - j]);
+}
+AMDMSM_DEV void load_coord_disk(Fp<FQ, false>& r, const uint32_t* src) { load_be_raw(r, src); }
+template <int NR>
+AMDMSM_DEV void load_coord_disk(Fp2<FQ, NR, false>& r, const uint32_t* src) {
+    load_be_raw(r.c0, src);
+    load_be_raw(r.c1, src + FQ::N);
+}
+
+__global__ void __launch_bounds__(TPB) k_disk_decode(const uint32_t* __restrict__ src, size_t n, uint32_t* __restrict__ dst) {
+    const size_t i = gtid();
+    if (i >= n) return;
+    Aff<E> a;
+    load_coord_disk(a.x, src + i * AFFW);
+    load_coord_disk(a.y, src + i * AFFW + EW);
+    E one;
+    el_one(one);
+    if (el_is_zero(a.x) && el_eq(a.y, one)) el_zero(a.y);   // (0, one) is zero (curve_serialization.tcc:95-99)
+    store_aff(dst + i * AFFW, a);
+}
+
 // ------------------------------------------------- fixed-base exponentiation
 // batch_exp / batch_exp_with_coeff (multiexp.tcc:874-947): res[i] = v[i] * g through a window
 // table powers_of_g[outer][inner] = inner * 2^(outer*window) * g (get_window_table,
@@ -932,7 +963,6 @@ __global__ void __launch_bounds__(TPB) k_fb_exp(const uint32_t* __restrict__ tab
 // libff's FFI wire format (ffi/ffi_serialization.hpp:12-16, .tcc:19-187): every prime-field
 // component is a big-endian plain (non-Montgomery) integer padded to the in-memory bigint
 // size, extension coefficients highest-order first, points are affine X || Y, zero = (0, 1).
-AMDMSM_DEV uint32_t bswap32(uint32_t v) { return __builtin_bswap32(v); }
 
 // one Fq component: BE bytes -> LE words; false when the value is not < modulus (:65-76)
 template <bool I>
@@ -1210,6 +1240,10 @@ void l_ffi_decode_scalars(hipStream_t st, const uint32_t* src, size_t n, uint32_
 void l_ffi_encode_point(hipStream_t st, const uint32_t* src_xyz, uint32_t* dst) {
     hipLaunchKernelGGL(k_ffi_encode_point, dim3(1), dim3(64), 0, st, src_xyz, dst);
 }
+void l_disk_decode(hipStream_t st, const uint32_t* src, size_t n, uint32_t* dst) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_disk_decode, dim3(blocks_for(n)), dim3(TPB), 0, st, src, n, dst);
+}
 // table: outerc * 2^window points, gouter: outerc points
 void l_fixed_base_exp(hipStream_t st, const uint32_t* g_xyz, int scalar_size, int window, const uint32_t* scalars, size_t n,
                       int mont, const uint32_t* coeff, int form, uint32_t* gouter, uint32_t* table, uint32_t* out) {
@@ -1261,7 +1295,7 @@ void l_madd_bench(hipStream_t st, const uint32_t* pts, uint32_t* out, size_t nth
 const group_vtable g_vt = {
     GP::CURVE, GP::GROUP, FRW, EW, FR::BITS, GP::LIBFF_PROJECTIVE ? 1 : 0, FR::R,
     l_import_bases, l_count, l_scatter, l_sort, l_accumulate, l_reduce_segments, l_sum_butterfly, l_horner, l_sum_points,
-    l_gen_bases_seq, l_export_affine, l_ffi_decode_points, l_ffi_decode_scalars, l_ffi_encode_point, l_fixed_base_exp, l_field_op, l_group_op, l_digits, l_mul_bench, l_madd_bench,
+    l_gen_bases_seq, l_export_affine, l_ffi_decode_points, l_ffi_decode_scalars, l_ffi_encode_point, l_disk_decode, l_fixed_base_exp, l_field_op, l_group_op, l_digits, l_mul_bench, l_madd_bench,
 };
 
 }  // namespace

@@ -42,7 +42,7 @@ EXPORTED_SYMBOLS = [
     "amdmsm_device_count", "amdmsm_ctx_create", "amdmsm_ctx_destroy", "amdmsm_strerror",
     "amdmsm_last_error", "amdmsm_sizes", "amdmsm_plan", "amdmsm_pippenger_optimal_c",
     "amdmsm_bdlo12_signed_optimal_c", "amdmsm_multi_exp", "amdmsm_multi_exp_filter_one_zero",
-    "amdmsm_batch_to_special", "amdmsm_batch_exp", "amdmsm_import_bases_device", "amdmsm_export_affine_device",
+    "amdmsm_batch_to_special", "amdmsm_batch_exp", "amdmsm_multi_exp_stream", "amdmsm_multi_exp_stream_file", "amdmsm_import_bases_device", "amdmsm_export_affine_device",
     "amdmsm_msm_device", "amdmsm_sum_points_device", "amdmsm_gen_bases_seq_device",
     "amdmsm_set_timing", "amdmsm_get_timings", "amdmsm_set_pipeline_depth", "amdmsm_last_slot",
     "amdmsm_get_slot_timings", "amdmsm_field_op_device", "amdmsm_group_op_device",
@@ -218,6 +218,21 @@ class Engine:
                                               ctypes.c_size_t(elems.shape[0]))
         self._check(rc, "amdmsm_batch_to_special")
         return elems
+
+    def multi_exp_stream_file(self, curve, group, path, scalars, offset_bytes=0, chunk_points=0,
+                              out_form=OUT_AFFINE, scalars_plain=False):
+        """libff::multi_exp_stream<form_montgomery, compression_off> (multiexp_stream.tcc:164-191) with
+        the base elements read from ``path`` in libff's on-disk format."""
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint64)
+        s = sizes(curve, group)
+        out = np.zeros(s["g_bytes"] // 8, dtype=np.uint64)
+        o = self._opts(out_form=out_form, scalars_plain=scalars_plain)
+        rc = self.lib.amdmsm_multi_exp_stream_file(self.h, curve, group, path.encode(), ctypes.c_size_t(offset_bytes),
+                                                   _np_ptr(scalars) if scalars.shape[0] else None,
+                                                   ctypes.c_size_t(scalars.shape[0]), ctypes.c_size_t(chunk_points),
+                                                   _np_ptr(out), ctypes.byref(o))
+        self._check(rc, "amdmsm_multi_exp_stream_file")
+        return out
 
     def batch_exp(self, curve, group, scalar_size, window, g, v, coeff=None, scalars_plain=False):
         """libff::batch_exp / batch_exp_with_coeff (multiexp.tcc:874-947) for the table that

@@ -1241,6 +1241,31 @@ int orc_batch_exp(int curve, int group, size_t scalar_size, size_t window, const
     return 0;
 }
 
+/* -------------------------------------------------------- on-disk base records */
+/* group_element_codec<encoding_binary, form_montgomery, compression_off>::write
+ * (curve_serialization.tcc:78-101) over field_element_codec (field_serialization.tcc:124-146,
+ * 197-223): affine X || Y, components c0, c1, each the byte-reversed Montgomery bigint. */
+int orc_disk_write(int curve, int group, size_t n, const uint64_t *elems, uint8_t *out)
+{
+    const orc_group *g = find_group(curve, group);
+    if (!g) return -2;
+    ctx_t c = mkctx(g);
+    const int gl = GLIMBS(&c);
+    const size_t cb = (size_t)c.n * 8;
+    for (size_t i = 0; i < n; ++i) {
+        uint64_t aff[MAXG];
+        g_to_affine(&c, aff, elems + i * gl);
+        for (int coord = 0; coord < 2; ++coord) {
+            for (int k = 0; k < c.deg; ++k) {
+                const uint8_t *src = (const uint8_t *)(aff + coord * c.en + k * c.n);
+                uint8_t *dst = out + ((i * 2 + (size_t)coord) * (size_t)c.deg + (size_t)k) * cb;
+                for (size_t b = 0; b < cb; ++b) dst[b] = src[cb - 1 - b];
+            }
+        }
+    }
+    return 0;
+}
+
 /* ------------------------------------------------------------ FFI codecs */
 /* object_write_to_buffer / field_serializer, ffi_serialization.tcc:19-136:
  * big-endian plain bigint, extension coefficients highest-order first. */

@@ -66,6 +66,9 @@ int orc_batch_to_special(int curve, int group, size_t n, uint64_t *elems);
 int orc_batch_exp(int curve, int group, size_t scalar_size, size_t window, const uint64_t *g, size_t n,
                   const uint64_t *scalars, const uint64_t *coeff, uint64_t *out);
 
+/* n elements -> libff's binary / Montgomery / uncompressed records (2 * coord bytes each) */
+int orc_disk_write(int curve, int group, size_t n, const uint64_t *elems, uint8_t *out);
+
 size_t orc_log2(size_t n);
 size_t orc_pippenger_optimal_c(size_t n);
 size_t orc_bdlo12_signed_optimal_c(size_t n);

@@ -175,6 +175,16 @@ def batch_exp(curve, group, scalar_size, window, g, v, coeff=None):
     return out
 
 
+def disk_write(curve, group, elems):
+    """libff on-disk records (binary, Montgomery, uncompressed) of the given elements, as bytes"""
+    s = sizes(curve, group)
+    elems = _u64(elems)
+    n = elems.shape[0]
+    out = np.zeros(n * 2 * s["coord_bytes"], dtype=np.uint8)
+    assert lib().orc_disk_write(curve, group, ctypes.c_size_t(n), _p(elems), _p(out)) == 0
+    return out
+
+
 def bdlo12_signed_optimal_c(n):
     return int(lib().orc_bdlo12_signed_optimal_c(ctypes.c_size_t(n)))
 

@@ -182,6 +182,27 @@ def batch_exp(curve, group, scalar_size, window, g, v, coeff=None):
     return out
 
 
+def disk_write(curve, group, elems):
+    s = sizes(curve, group)
+    elems = np.ascontiguousarray(elems, dtype=np.uint64)
+    n = elems.shape[0]
+    out = np.zeros(n * 2 * s["coord_bytes"], dtype=np.uint8)
+    lib().ref_disk_write.restype = ctypes.c_size_t
+    got = lib().ref_disk_write(curve, group, ctypes.c_size_t(n), _p(elems), _p(out), ctypes.c_size_t(out.size))
+    assert got == out.size, (got, out.size)
+    return out
+
+
+def multi_exp_stream(curve, group, disk_bytes, scalars):
+    s = sizes(curve, group)
+    disk_bytes = np.ascontiguousarray(disk_bytes, dtype=np.uint8)
+    scalars = np.ascontiguousarray(scalars, dtype=np.uint64)
+    out = np.zeros(s["g_bytes"] // 8, dtype=np.uint64)
+    assert lib().ref_multi_exp_stream(curve, group, ctypes.c_size_t(scalars.shape[0]), _p(disk_bytes),
+                                      ctypes.c_size_t(disk_bytes.size), _p(scalars), _p(out)) == 0
+    return out
+
+
 def bdlo12_signed_optimal_c(n):
     return int(lib().ref_bdlo12_signed_optimal_c(ctypes.c_size_t(n)))
 

@@ -23,12 +23,15 @@
 #include <libff/algebra/curves/bls12_381/bls12_381_pp.hpp>
 #include <libff/algebra/curves/bw6_761/bw6_761_pp.hpp>
 #include <libff/algebra/fields/field_utils.hpp>
+#include <libff/algebra/curves/curve_serialization.hpp>
 #include <libff/algebra/scalar_multiplication/multiexp.hpp>
+#include <libff/algebra/scalar_multiplication/multiexp_stream.hpp>
 #include <libff/common/profiling.hpp>
 #include <libff/common/rng.hpp>
 
 #include <chrono>
 #include <cstring>
+#include <sstream>
 #include <vector>
 
 using namespace libff;
@@ -252,6 +255,32 @@ template<typename G, typename Fr> struct ops {
         return field_get_digit(bi, c, idx);
     }
 
+    // on-disk records as profile_multiexp.cpp:100-150 writes them, and multi_exp_stream over them
+    static size_t disk_write(size_t n, const void *elems, void *out, size_t cap)
+    {
+        std::ostringstream os(std::ios_base::out | std::ios_base::binary);
+        const G *e = (const G *)elems;
+        for (size_t i = 0; i < n; ++i) {
+            G tmp;
+            memcpy((void *)&tmp, (const void *)&e[i], sizeof(G));
+            group_write<encoding_binary, form_montgomery, compression_off>(tmp, os);
+        }
+        const std::string s = os.str();
+        if (s.size() > cap) return 0;
+        memcpy(out, s.data(), s.size());
+        return s.size();
+    }
+    static int stream_c(size_t n, const void *bytes, size_t nbytes, const void *scalars, void *out_affine)
+    {
+        std::istringstream is(std::string((const char *)bytes, nbytes), std::ios_base::in | std::ios_base::binary);
+        std::vector<Fr> s(n);
+        memcpy((void *)s.data(), scalars, n * sizeof(Fr));
+        G r = multi_exp_stream<form_montgomery, compression_off, G, Fr>(is, s);
+        r.to_affine_coordinates();
+        memcpy(out_affine, (const void *)&r, sizeof(G));
+        return 0;
+    }
+
     // get_window_table + batch_exp / batch_exp_with_coeff (multiexp.tcc:809-947)
     static int batch_exp_c(
         size_t scalar_size, size_t window, const void *g_in, size_t n, const void *scalars, const void *coeff, void *out)
@@ -468,6 +497,21 @@ int ref_batch_exp(
 {
     int rc = 0;
     DISPATCH(curve, group, rc = O::batch_exp_c(scalar_size, window, g, n, scalars, coeff, out));
+    return rc;
+}
+
+size_t ref_disk_write(int curve, int group, size_t n, const void *elems, void *out, size_t cap)
+{
+    size_t r = 0;
+    DISPATCH(curve, group, r = O::disk_write(n, elems, out, cap));
+    return r;
+}
+
+int ref_multi_exp_stream(
+    int curve, int group, size_t n, const void *bytes, size_t nbytes, const void *scalars, void *out_affine)
+{
+    int rc = 0;
+    DISPATCH(curve, group, rc = O::stream_c(n, bytes, nbytes, scalars, out_affine));
     return rc;
 }
 

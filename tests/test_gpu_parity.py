@@ -373,3 +373,35 @@ def test_normal_form_bases_batched_inversion(engine, port, name, curve, group):
     got = engine.multi_exp(curve, group, mixed, sc, base_form=multi_exp_base_form_normal)
     assert (got == want).all()
     assert (engine.batch_to_special(curve, group, mixed) == port.batch_to_special(curve, group, mixed)).all()
+
+
+@pytest.mark.parametrize("name,curve,group", GROUPS)
+def test_multi_exp_stream_from_file(engine, port, name, curve, group, tmp_path):
+    """multi_exp_stream (multiexp_stream.tcc:164-191): bases read from a file of libff's on-disk
+    records (binary / Montgomery / uncompressed), several chunks with a ragged tail, a zero
+    element inside; and the golden byte layout decoded on the device."""
+    g = golden()
+    n = 3500 if curve != 2 and group == 1 else 900
+    bases = port.bases_seq(curve, group, n, first=8)
+    bases[17] = port.group_consts(curve, group)[1]
+    sc = port.scalars_sha512(curve, 2024, n)
+    path = tmp_path / f"{name}.bin"
+    hdr = 24   # the C ABI takes a byte offset (e.g. to skip a header)
+    path.write_bytes(bytes(hdr) + port.disk_write(curve, group, bases).tobytes())
+    want = port.multi_exp(curve, group, bases, sc, port.BDLO12_SIGNED, 1, chunks=4, omp=True)
+    for chunk in (1000, 0, 256):
+        got = engine.multi_exp_stream_file(curve, group, str(path), sc, offset_bytes=hdr, chunk_points=chunk)
+        assert (got == want).all(), chunk
+    # golden bytes (written by the reference) through the same decoder
+    gp = tmp_path / f"{name}_golden.bin"
+    gp.write_bytes(g[f"{name}/disk_bytes"].tobytes())
+    sc6 = port.scalars_sha512(curve, 60, 6)
+    want6 = port.multi_exp(curve, group, g[f"{name}/disk_elems"], sc6, port.BDLO12_SIGNED, 0)
+    assert (engine.multi_exp_stream_file(curve, group, str(gp), sc6) == want6).all()
+    if f"{name}/disk_stream_msm" in g:
+        assert (want6 == g[f"{name}/disk_stream_msm"]).all()
+    # a truncated file is an error, not a wrong answer
+    tp = tmp_path / f"{name}_short.bin"
+    tp.write_bytes(g[f"{name}/disk_bytes"].tobytes()[:-5])
+    with pytest.raises(libff_amd.AmdMsmError):
+        engine.multi_exp_stream_file(curve, group, str(tp), sc6)

@@ -186,3 +186,15 @@ def test_batch_exp(port, name, curve, group):
         assert (port.batch_exp(curve, group, bits, w, gb, v) == g[f"{name}/bexp_w{w}"]).all()
     r = port.batch_exp(curve, group, bits, 4, gb, v, coeff=v[5])
     assert (np.stack([port.group_op(curve, group, 4, x) for x in r]) == g[f"{name}/bexp_coeff_w4_affine"]).all()
+
+
+@pytest.mark.parametrize("name,curve,group", GROUPS)
+def test_on_disk_base_records(port, name, curve, group):
+    """group_write<encoding_binary, form_montgomery, compression_off> byte layout and
+    multi_exp_stream over it (multiexp_stream.tcc:164-191)."""
+    g = golden()
+    elems = g[f"{name}/disk_elems"]
+    assert (port.disk_write(curve, group, elems) == g[f"{name}/disk_bytes"]).all()
+    if f"{name}/disk_stream_msm" in g:
+        sc = port.scalars_sha512(curve, 60, 6)
+        assert (port.multi_exp(curve, group, elems, sc, port.BDLO12_SIGNED, 0) == g[f"{name}/disk_stream_msm"]).all()
