@@ -15,10 +15,14 @@
 #include <libff/common/profiling.hpp>
 #include <libff/common/rng.hpp>
 
+#include <libff/algebra/curves/curve_serialization.hpp>
+
 #include <libff_amd/multiexp.hpp>
+#include <libff_amd/multiexp_stream.hpp>
 
 #include <algorithm>
 #include <cstdio>
+#include <sstream>
 #include <vector>
 
 using namespace libff;
@@ -66,6 +70,16 @@ template<typename G, typename Fr> void check_group(const char *name, const std::
             for (size_t i = 0; i < v.size(); ++i) {
                 ok = ok && (dev[i] == cpu[i]) && (devc[i] == cpuc[i]);
             }
+        }
+        // streaming MSM: the reference's own writer produces the on-disk records, the routed
+        // multi_exp_stream consumes them on the device (multiexp_stream.hpp:25-27)
+        {
+            std::stringstream ss(std::ios_base::in | std::ios_base::out | std::ios_base::binary);
+            for (const G &b : special) {
+                group_write<encoding_binary, form_montgomery, compression_off>(b, ss);
+            }
+            const G rs = multi_exp_stream<form_montgomery, compression_off, G, Fr>(ss, scalars);
+            ok = ok && (expect == rs);
         }
         printf("%-14s n=%-6zu %s\n", name, n, ok ? "ok" : "MISMATCH");
         if (!ok) {
