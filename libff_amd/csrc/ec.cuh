@@ -186,6 +186,188 @@ AMDMSM_DEV void jac_to_aff(Aff<E>& r, const Jac<E>& p) {
     el_mul(r.y, p.y, z2);
 }
 
+// ---- extended Jacobian ("XYZZ") accumulators --------------------------------------------
+// (X, Y, ZZ, ZZZ) with x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2; infinity: ZZ == 0.  Bucket sums live
+// in this form: a mixed addition costs 8M + 2S and 7 linear operations (madd-2008-s) against
+// 7M + 4S and 13 for the Jacobian formula libff uses (alt_bn128_g1.cpp:208-283), and a full
+// addition 12M + 2S (add-2008-s) against 16.  Same group element; the representation never
+// leaves the device.  Doubling-heavy code (scalar multiples, the Horner over windows) converts to
+// Jacobian, where doubling is cheaper.
+template <class E>
+struct Xyzz {
+    E x, y, zz, zzz;
+};
+
+template <class E>
+AMDMSM_DEV void xyzz_set_inf(Xyzz<E>& p) {
+    el_zero(p.x);
+    el_zero(p.y);
+    el_zero(p.zz);
+    el_zero(p.zzz);
+}
+
+template <class E>
+AMDMSM_DEV bool xyzz_is_inf(const Xyzz<E>& p) {
+    return el_is_zero(p.zz);
+}
+
+// 2 * (affine p), mdbl-2008-s-1 with a = 0: 3M + 3S... written with products only
+template <class E>
+AMDMSM_DEV void xyzz_dbl_affine(Xyzz<E>& r, const Aff<E>& p) {
+    E u, v, w, s, m, t;
+    el_dbl(u, p.y);            // U = 2*Y1
+    el_sqr(v, u);              // V = U^2
+    el_mul(w, u, v);           // W = U*V
+    el_mul(s, p.x, v);         // S = X1*V
+    el_sqr(m, p.x);
+    el_dbl(t, m);
+    el_add(m, t, m);           // M = 3*X1^2
+    el_sqr(t, m);
+    el_sub(t, t, s);
+    el_sub(r.x, t, s);         // X3 = M^2 - 2S
+    el_sub(s, s, r.x);
+    el_mul(s, m, s);
+    el_mul(t, w, p.y);
+    el_sub(r.y, s, t);         // Y3 = M*(S - X3) - W*Y1
+    r.zz = v;
+    r.zzz = w;
+}
+
+// 2 * a, dbl-2008-s-1 with a = 0 (6M + 3S)
+template <class E>
+AMDMSM_DEV void xyzz_dbl(Xyzz<E>& r, const Xyzz<E>& a) {
+    if (xyzz_is_inf(a)) {
+        r = a;
+        return;
+    }
+    E u, v, w, s, m, t;
+    el_dbl(u, a.y);
+    el_sqr(v, u);
+    el_mul(w, u, v);
+    el_mul(s, a.x, v);
+    el_sqr(m, a.x);
+    el_dbl(t, m);
+    el_add(m, t, m);
+    el_sqr(t, m);
+    el_sub(t, t, s);
+    el_mul(u, w, a.y);         // W*Y1 (before Y is overwritten)
+    el_sub(r.x, t, s);
+    el_sub(s, s, r.x);
+    el_mul(s, m, s);
+    el_sub(r.y, s, u);
+    el_mul(r.zz, v, a.zz);
+    el_mul(r.zzz, w, a.zzz);
+}
+
+// acc += P (P affine), madd-2008-s with the special-case ladder of G::mixed_add
+template <class E>
+AMDMSM_DEV void xyzz_madd(Xyzz<E>& acc, const Aff<E>& p) {
+    if (aff_is_inf(p)) return;
+    if (xyzz_is_inf(acc)) {
+        acc.x = p.x;
+        acc.y = p.y;
+        el_one(acc.zz);
+        el_one(acc.zzz);
+        return;
+    }
+    E pp, r, ppp, q, t;
+    el_mul(pp, p.x, acc.zz);      // U2
+    el_mul(r, p.y, acc.zzz);      // S2
+    el_sub(pp, pp, acc.x);        // P = U2 - X1
+    el_sub(r, r, acc.y);          // R = S2 - Y1
+    if (el_is_zero(pp)) {
+        if (el_is_zero(r)) {
+            xyzz_dbl_affine(acc, p);   // same point: 2*P
+        } else {
+            xyzz_set_inf(acc);         // opposite points
+        }
+        return;
+    }
+    el_mul(ppp, pp, pp);          // PP (kept in ppp for a moment)
+    el_mul(q, acc.x, ppp);        // Q = X1*PP
+    el_mul(acc.zz, acc.zz, ppp);  // ZZ3 = ZZ1*PP
+    el_mul(ppp, pp, ppp);         // PPP = P*PP
+    el_mul(acc.zzz, acc.zzz, ppp);   // ZZZ3 = ZZZ1*PPP
+    el_sqr(t, r);
+    el_sub(t, t, ppp);
+    el_sub(t, t, q);
+    el_sub(acc.x, t, q);          // X3 = R^2 - PPP - 2Q
+    el_sub(q, q, acc.x);
+    el_mul(q, r, q);              // R*(Q - X3)
+    el_mul(t, acc.y, ppp);        // Y1*PPP
+    el_sub(acc.y, q, t);          // Y3
+}
+
+// r = a + b, add-2008-s (r may alias a)
+template <class E>
+AMDMSM_DEV void xyzz_add(Xyzz<E>& r, const Xyzz<E>& a, const Xyzz<E>& b) {
+    if (xyzz_is_inf(a)) {
+        r = b;
+        return;
+    }
+    if (xyzz_is_inf(b)) {
+        r = a;
+        return;
+    }
+    E u1, s1, pp, rr, ppp, q, t;
+    el_mul(u1, a.x, b.zz);
+    el_mul(pp, b.x, a.zz);
+    el_mul(s1, a.y, b.zzz);
+    el_mul(rr, b.y, a.zzz);
+    el_sub(pp, pp, u1);           // P = U2 - U1
+    el_sub(rr, rr, s1);           // R = S2 - S1
+    if (el_is_zero(pp)) {
+        if (el_is_zero(rr)) {
+            xyzz_dbl(r, a);
+        } else {
+            xyzz_set_inf(r);
+        }
+        return;
+    }
+    el_sqr(ppp, pp);              // PP
+    el_mul(q, u1, ppp);           // Q = U1*PP
+    el_mul(t, a.zz, b.zz);
+    el_mul(r.zz, t, ppp);         // ZZ3 = ZZ1*ZZ2*PP
+    el_mul(ppp, pp, ppp);         // PPP
+    el_mul(t, a.zzz, b.zzz);
+    el_mul(r.zzz, t, ppp);        // ZZZ3 = ZZZ1*ZZZ2*PPP
+    el_sqr(t, rr);
+    el_sub(t, t, ppp);
+    el_sub(t, t, q);
+    el_sub(r.x, t, q);            // X3
+    el_sub(q, q, r.x);
+    el_mul(q, rr, q);
+    el_mul(t, s1, ppp);
+    el_sub(r.y, q, t);            // Y3
+}
+
+// Jacobian (X*ZZ^2, Y*ZZ^3, ZZZ): with ZZ = Z^2, ZZZ = Z^3 this is the scaling by lambda = ZZ
+template <class E>
+AMDMSM_DEV void xyzz_to_jac(Jac<E>& r, const Xyzz<E>& p) {
+    if (xyzz_is_inf(p)) {
+        jac_set_inf(r);
+        return;
+    }
+    E z2, z3;
+    el_sqr(z2, p.zz);
+    el_mul(z3, z2, p.zz);
+    el_mul(r.x, p.x, z2);
+    el_mul(r.y, p.y, z3);
+    r.z = p.zzz;
+}
+
+template <class E>
+AMDMSM_DEV void jac_to_xyzz(Xyzz<E>& r, const Jac<E>& p) {
+    if (jac_is_inf(p)) {
+        xyzz_set_inf(r);
+        return;
+    }
+    r.x = p.x;
+    r.y = p.y;
+    el_sqr(r.zz, p.z);
+    el_mul(r.zzz, r.zz, p.z);
+}
+
 template <class E>
 AMDMSM_DEV void jac_shfl_xor(Jac<E>& r, const Jac<E>& p, int mask) {
     el_shfl_xor(r.x, p.x, mask);

@@ -147,17 +147,18 @@ int make_plan(const group_vtable *vt, size_t n, int c_req, int L_req, plan_t &p,
     off = align_up(off + (size_t)p.W * p.B * 4, 256);
     p.off_lists = off;
     off = align_up(off + (size_t)p.W * p.list_stride * 4, 256);
+    const size_t zz_bytes = (size_t)4 * vt->el_words * 4;   // (X, Y, ZZ, ZZZ) bucket accumulators
     p.off_buckets = off;
-    off = align_up(off + (size_t)p.W * p.B * xyz_bytes, 256);
+    off = align_up(off + (size_t)p.W * p.B * zz_bytes, 256);
     const size_t M = p.B / p.L;
     p.off_lvl0 = off;
     off = align_up(off + (size_t)p.W * M * xyz_bytes, 256);
     p.off_lvl1 = off;
     off = align_up(off + (size_t)p.W * ((M + p.L - 1) / p.L) * xyz_bytes, 256);
     p.off_pfirst = off;
-    off = align_up(off + (size_t)p.W * p.T * xyz_bytes, 256);
+    off = align_up(off + (size_t)p.W * p.T * zz_bytes, 256);
     p.off_plast = off;
-    off = align_up(off + (size_t)p.W * p.T * xyz_bytes, 256);
+    off = align_up(off + (size_t)p.W * p.T * zz_bytes, 256);
     p.off_cont = off;
     off = align_up(off + (size_t)p.W * p.T * 4, 256);
     p.off_queue = off;
@@ -251,7 +252,7 @@ int msm_device_impl(amdmsm_ctx *ctx, const group_vtable *vt, const uint32_t *d_b
                  p.list_stride);
     }
     record(ctx, sl, 2, st);
-    HIP_TRY(ctx, hipMemsetAsync(buckets, 0, (size_t)p.W * p.B * vt->el_words * 12, st));
+    HIP_TRY(ctx, hipMemsetAsync(buckets, 0, (size_t)p.W * p.B * vt->el_words * 16, st));
     HIP_TRY(ctx, hipMemsetAsync(ws + p.off_queue, 0, 8, st));
     vt->accumulate(st, counts, lists, p.list_stride, d_bases, buckets, (uint32_t *)(ws + p.off_pfirst),
                    (uint32_t *)(ws + p.off_plast), (uint32_t *)(ws + p.off_cont), (uint32_t *)(ws + p.off_queue), p.W,

@@ -55,6 +55,7 @@ using EI = typename coord_sel<GP::DEG, true>::type;                      // prob
 constexpr int EW = FQ::N * GP::DEG;   // words per coordinate
 constexpr int AFFW = 2 * EW;          // words per compact affine point
 constexpr int XYZW = 3 * EW;          // words per (X, Y, Z) record
+constexpr int ZZW = 4 * EW;           // words per (X, Y, ZZ, ZZZ) bucket accumulator
 constexpr int FRW = FR::N;            // words per scalar
 constexpr int TPB = 256;
 
@@ -78,6 +79,18 @@ template <class T> AMDMSM_DEV void store_jac(uint32_t* q, const Jac<T>& p) {
     el_store(q, p.x);
     el_store(q + EW, p.y);
     el_store(q + 2 * EW, p.z);
+}
+template <class T> AMDMSM_DEV void load_xyzz(Xyzz<T>& p, const uint32_t* q) {
+    el_load(p.x, q);
+    el_load(p.y, q + EW);
+    el_load(p.zz, q + 2 * EW);
+    el_load(p.zzz, q + 3 * EW);
+}
+template <class T> AMDMSM_DEV void store_xyzz(uint32_t* q, const Xyzz<T>& p) {
+    el_store(q, p.x);
+    el_store(q + EW, p.y);
+    el_store(q + 2 * EW, p.zz);
+    el_store(q + 3 * EW, p.zzz);
 }
 
 // libff in-memory record -> engine Jacobian
@@ -556,15 +569,15 @@ __global__ void __launch_bounds__(TPB) k_accumulate(const uint32_t* __restrict__
     uint32_t bend = e[b];
     bool from_prev = (b ? e[b - 1] : 0u) < lo;   // first piece continues a bucket begun earlier
     const uint32_t* lst = lists + w * list_stride;
-    uint32_t* bk = buckets + w * (size_t)B * XYZW;
-    Jac<EH> acc;
-    jac_set_inf(acc);
+    uint32_t* bk = buckets + w * (size_t)B * ZZW;
+    Xyzz<EH> acc;
+    xyzz_set_inf(acc);
     for (uint32_t k = lo; k < hi; ++k) {
         if (k == bend) {
             // bucket b ends here: it is complete unless its head lies in an earlier lane
-            store_jac(from_prev ? part_first + g * XYZW : bk + (size_t)b * XYZW, acc);
+            store_xyzz(from_prev ? part_first + g * ZZW : bk + (size_t)b * ZZW, acc);
             from_prev = false;
-            jac_set_inf(acc);
+            xyzz_set_inf(acc);
             do {
                 ++b;
                 bend = e[b];
@@ -574,16 +587,16 @@ __global__ void __launch_bounds__(TPB) k_accumulate(const uint32_t* __restrict__
         Aff<EH> p;
         load_aff(p, bases + (size_t)(ent & 0x7fffffffu) * AFFW);
         el_cneg(p.y, p.y, (ent >> 31) != 0);   // -(x, y) = (x, -y); (0,0) stays infinity
-        jac_madd(acc, p);
+        xyzz_madd(acc, p);
     }
     if (bend == hi) {   // the last bucket ends exactly with the lane
-        store_jac(from_prev ? part_first + g * XYZW : bk + (size_t)b * XYZW, acc);
+        store_xyzz(from_prev ? part_first + g * ZZW : bk + (size_t)b * ZZW, acc);
         cont_bucket[g] = NO_BUCKET;
     } else if (from_prev) {   // the whole lane lies inside one bucket
-        store_jac(part_first + g * XYZW, acc);
+        store_xyzz(part_first + g * ZZW, acc);
         cont_bucket[g] = NO_BUCKET;
     } else {   // bucket b starts in this lane and continues
-        store_jac(part_last + g * XYZW, acc);
+        store_xyzz(part_last + g * ZZW, acc);
         cont_bucket[g] = b;
     }
 }
@@ -614,13 +627,13 @@ __global__ void __launch_bounds__(64) k_accumulate_fixup(const uint32_t* __restr
         long_queue[3 + 2 * (size_t)slot] = (uint32_t)(g >> 32);
         return;
     }
-    Jac<E> acc, x;
-    load_jac(acc, part_last + g * XYZW);
+    Xyzz<E> acc, x;
+    load_xyzz(acc, part_last + g * ZZW);
     for (uint32_t u = t + 1; u <= t_last; ++u) {
-        load_jac(x, part_first + (w * T + u) * XYZW);
-        jac_add(acc, acc, x);
+        load_xyzz(x, part_first + (w * T + u) * ZZW);
+        xyzz_add(acc, acc, x);
     }
-    store_jac(buckets + (w * B + b) * XYZW, acc);
+    store_xyzz(buckets + (w * B + b) * ZZW, acc);
 }
 
 // one wave per queued bucket: lanes stride over its partials, XOR butterfly, lane 0 stores
@@ -639,14 +652,17 @@ __global__ void __launch_bounds__(64) k_accumulate_fixup_long(const uint32_t* __
         const uint32_t t = (uint32_t)(g % T);
         const uint32_t b = cont_bucket[g];
         const uint32_t t_last = (ends[w * B + b] - 1) / S;
-        Jac<E> acc, x;
-        if (lane == 0) load_jac(acc, part_last + g * XYZW); else jac_set_inf(acc);
+        Xyzz<E> acc, x;
+        if (lane == 0) load_xyzz(acc, part_last + g * ZZW); else xyzz_set_inf(acc);
         for (uint32_t u = t + 1 + lane; u <= t_last; u += 64) {
-            load_jac(x, part_first + (w * T + u) * XYZW);
-            jac_add(acc, acc, x);
+            load_xyzz(x, part_first + (w * T + u) * ZZW);
+            xyzz_add(acc, acc, x);
         }
-        wave_group_sum(acc, 64);
-        if (lane == 0) store_jac(buckets + (w * B + b) * XYZW, acc);
+        Jac<E> j;
+        xyzz_to_jac(j, acc);
+        wave_group_sum(j, 64);
+        jac_to_xyzz(acc, j);
+        if (lane == 0) store_xyzz(buckets + (w * B + b) * ZZW, acc);
     }
 }
 
@@ -678,12 +694,17 @@ __global__ void __launch_bounds__(64) k_reduce_segments(const uint32_t* __restri
     jac_set_inf(acc);
     jac_set_inf(sum);
     if (valid) {
-        const uint32_t* seg = buckets + (w * B + (size_t)s * L) * XYZW;
+        const uint32_t* seg = buckets + (w * B + (size_t)s * L) * ZZW;
+        Xyzz<E> xa, xs, xb;
+        xyzz_set_inf(xa);
+        xyzz_set_inf(xs);
         for (uint32_t j = L; j-- > 0;) {
-            load_jac(bk, seg + (size_t)j * XYZW);
-            jac_add(acc, acc, bk);    // acc = sum_{k >= j} B_k
-            jac_add(sum, sum, acc);   // sum = sum_k (k - j + 1) B_k
+            load_xyzz(xb, seg + (size_t)j * ZZW);
+            xyzz_add(xa, xa, xb);    // xa = sum_{k >= j} B_k
+            xyzz_add(xs, xs, xa);    // xs = sum_k (k - j + 1) B_k
         }
+        xyzz_to_jac(acc, xa);
+        xyzz_to_jac(sum, xs);
         // segment's buckets carry weights s*L + j + 1: add (s*L) * acc
         jac_mul_u64(bk, acc, (unsigned long long)s * L);
         jac_add(sum, sum, bk);
@@ -1145,6 +1166,21 @@ __global__ void __launch_bounds__(TPB) k_mul_bench(uint32_t* __restrict__ inout,
 }
 
 template <class T>
+__global__ void __launch_bounds__(TPB) k_xyzz_madd_bench(const uint32_t* __restrict__ pts, uint32_t* __restrict__ out,
+                                                         size_t nthreads, int iters) {
+    const size_t i = gtid();
+    if (i >= nthreads) return;
+    Aff<T> p;
+    load_aff(p, pts + i * AFFW);
+    Xyzz<T> acc;
+    xyzz_dbl_affine(acc, p);
+    for (int k = 0; k < iters; ++k) xyzz_madd(acc, p);
+    Jac<T> j;
+    xyzz_to_jac(j, acc);
+    store_jac(out + i * XYZW, j);
+}
+
+template <class T>
 __global__ void __launch_bounds__(TPB) k_madd_bench(const uint32_t* __restrict__ pts, uint32_t* __restrict__ out,
                                                     size_t nthreads, int iters) {
     const size_t i = gtid();
@@ -1283,6 +1319,10 @@ void l_mul_bench(hipStream_t st, uint32_t* inout, size_t nthreads, int iters, in
 }
 void l_madd_bench(hipStream_t st, const uint32_t* pts, uint32_t* out, size_t nthreads, int iters, int inline_variant) {
     if (!nthreads) return;
+    if (inline_variant == 2) {
+        hipLaunchKernelGGL(k_xyzz_madd_bench<EH>, dim3(blocks_for(nthreads)), dim3(TPB), 0, st, pts, out, nthreads, iters);
+        return;
+    }
 #if AMDMSM_BENCH_BOTH
     if (inline_variant) {
         hipLaunchKernelGGL(k_madd_bench<EI>, dim3(blocks_for(nthreads)), dim3(TPB), 0, st, pts, out, nthreads, iters);

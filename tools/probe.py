@@ -44,6 +44,12 @@ def main():
             madds = nthreads * iters
             print(f"{name:14s} jac_madd {'inline' if variant else 'call  '}: {ms.value:8.3f} ms  "
                   f"{madds / ms.value / 1e6:9.3f} G madd/s")
+            if variant == 1:
+                eng.h2d(d_aff, aff)
+                for _ in range(2):
+                    eng._check(lib.amdmsm_madd_bench_device(eng.h, curve, group, d_aff, d_out, ctypes.c_size_t(nthreads),
+                                                            iters, 2, ctypes.byref(ms)), "madd_bench")
+                print(f"{name:14s} xyzz_madd (hot) : {ms.value:8.3f} ms  {madds / ms.value / 1e6:9.3f} G madd/s")
         eng.free(d_aff)
         eng.free(d_out)
 
