@@ -91,7 +91,7 @@ def pmc_traffic(curve_name, group, log2n, window_bits):
     import glob
 
     best = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_*.json"))):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*pmc*.json"))):
         try:
             d = json.load(open(path))
             wl = d["workload"]

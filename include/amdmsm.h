@@ -82,10 +82,10 @@ typedef struct amdmsm_opts {
 #define AMDMSM_MAX_PHASES 8
 /* phase indices of amdmsm_get_timings */
 enum {
-    AMDMSM_PH_COUNT = 0,   /* recode + histogram + scan */
-    AMDMSM_PH_SCATTER = 1, /* recode + scatter */
-    AMDMSM_PH_ACCUM = 2,   /* bucket accumulation (dominant kernel) */
-    AMDMSM_PH_REDUCE = 3,  /* bucket reduction levels */
+    AMDMSM_PH_COUNT = 0,   /* workspace clears (and the histogram pass of the fallback sort) */
+    AMDMSM_PH_SCATTER = 1, /* bucket sort: digits, coarse and fine partition (+ bucket zero-fill) */
+    AMDMSM_PH_ACCUM = 2,   /* k_accumulate alone (dominant kernel) */
+    AMDMSM_PH_REDUCE = 3,  /* spanning-bucket fix-up + bucket reduction levels */
     AMDMSM_PH_FINAL = 4,   /* Horner over windows */
     AMDMSM_PH_TOTAL = 5
 };

@@ -251,13 +251,11 @@ int msm_device_impl(amdmsm_ctx *ctx, const group_vtable *vt, const uint32_t *d_b
                  (int32_t *)lists, (uint32_t *)(ws + p.off_tmp_payload), (uint32_t *)(ws + p.off_tmp_key), counts, lists,
                  p.list_stride);
     }
-    record(ctx, sl, 2, st);
     HIP_TRY(ctx, hipMemsetAsync(buckets, 0, (size_t)p.W * p.B * vt->el_words * 16, st));
     HIP_TRY(ctx, hipMemsetAsync(ws + p.off_queue, 0, 8, st));
     vt->accumulate(st, counts, lists, p.list_stride, d_bases, buckets, (uint32_t *)(ws + p.off_pfirst),
                    (uint32_t *)(ws + p.off_plast), (uint32_t *)(ws + p.off_cont), (uint32_t *)(ws + p.off_queue), p.W,
-                   p.B, p.S, p.T);
-    record(ctx, sl, 3, st);
+                   p.B, p.S, p.T, ctx->timing ? sl.ev[2] : nullptr, ctx->timing ? sl.ev[3] : nullptr);
     vt->reduce_segments(st, buckets, p.W, p.B, p.L, lvl0);
     uint32_t M = p.B / p.L;
     M /= std::min<uint32_t>(M, 64u);   // folded per wave inside reduce_segments

@@ -43,7 +43,8 @@ struct group_vtable {
     // long_queue: 2 + 2*(W*T/24 + 1) words, word 0 zeroed (queue of buckets spanning many lanes)
     void (*accumulate)(hipStream_t, const uint32_t* ends, const uint32_t* lists, size_t list_stride,
                        const uint32_t* bases_affine, uint32_t* buckets, uint32_t* part_first, uint32_t* part_last,
-                       uint32_t* cont_bucket, uint32_t* long_queue, int W, uint32_t B, uint32_t S, uint32_t T);
+                       uint32_t* cont_bucket, uint32_t* long_queue, int W, uint32_t B, uint32_t S, uint32_t T,
+                       hipEvent_t before_main, hipEvent_t after_main);   // events bracket k_accumulate alone (may be null)
     // M = B/L segments per window, G = min(M, 64):
     // out[w][g] = sum over segments s in [g*G, (g+1)*G) of sum_j (s*L + j + 1) * bucket[w][s*L + j]
     void (*reduce_segments)(hipStream_t, const uint32_t* buckets, int W, uint32_t B, uint32_t L, uint32_t* out);

@@ -1236,9 +1236,12 @@ void l_sort(hipStream_t st, const uint32_t* scalars, size_t n, int mont, int c, 
 }
 void l_accumulate(hipStream_t st, const uint32_t* ends, const uint32_t* lists, size_t list_stride, const uint32_t* bases,
                   uint32_t* buckets, uint32_t* part_first, uint32_t* part_last, uint32_t* cont_bucket,
-                  uint32_t* long_queue, int W, uint32_t B, uint32_t S, uint32_t T) {
+                  uint32_t* long_queue, int W, uint32_t B, uint32_t S, uint32_t T, hipEvent_t before_main,
+                  hipEvent_t after_main) {
+    if (before_main) (void)hipEventRecord(before_main, st);
     hipLaunchKernelGGL(k_accumulate, dim3(blocks_for((size_t)W * T)), dim3(TPB), 0, st, ends, lists, list_stride, bases,
                        buckets, part_first, part_last, cont_bucket, W, B, S, T);
+    if (after_main) (void)hipEventRecord(after_main, st);
     hipLaunchKernelGGL(k_accumulate_fixup, dim3(blocks_for((size_t)W * T, 64)), dim3(64), 0, st, ends, part_first,
                        part_last, cont_bucket, buckets, long_queue, W, B, S, T);
     const size_t max_long = (size_t)W * T / LONG_SPAN + 1;
