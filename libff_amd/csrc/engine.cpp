@@ -91,7 +91,7 @@ struct plan_t {
     uint32_t S = 0, T = 0;   // entries per accumulation lane, lanes per window
     size_t off_counts = 0, off_lists = 0, off_buckets = 0, off_lvl0 = 0, off_lvl1 = 0, total = 0;
     size_t off_pfirst = 0, off_plast = 0, off_cont = 0, off_queue = 0;
-    size_t off_coarse = 0, off_cursor = 0, off_tmp_payload = 0, off_tmp_key = 0;
+    size_t off_coarse = 0, off_cursor = 0, off_tmp_payload = 0, off_tmp_key = 0, off_big = 0;
     size_t list_stride = 0;
 };
 
@@ -177,6 +177,8 @@ int make_plan(const group_vtable *vt, size_t n, int c_req, int L_req, plan_t &p,
     off = align_up(off + (size_t)p.W * p.list_stride * 4, 256);
     p.off_tmp_key = off;
     off = align_up(off + (size_t)p.W * p.list_stride * 4, 256);
+    p.off_big = off;
+    if (p.c <= 22) off = align_up(off + sort_geometry(n, p.c, p.W).big_words * 4, 256);
     p.total = off;
     return AMDMSM_OK;
 }
@@ -251,10 +253,11 @@ int msm_device_impl(amdmsm_ctx *ctx, const group_vtable *vt, const uint32_t *d_b
         vt->scatter(st, d_scalars, n, mont, p.c, p.W, counts, lists, p.list_stride);
     } else {
         HIP_TRY(ctx, hipMemsetAsync(ws + p.off_coarse, 0, (size_t)p.W * 1025 * 4, st));
+        HIP_TRY(ctx, hipMemsetAsync(ws + p.off_big, 0, 16, st));
         record(ctx, sl, 1, st);
         vt->sort(st, d_scalars, n, mont, p.c, p.W, (uint32_t *)(ws + p.off_coarse), (uint32_t *)(ws + p.off_cursor),
                  (int32_t *)lists, (uint32_t *)(ws + p.off_tmp_payload), (uint32_t *)(ws + p.off_tmp_key), counts, lists,
-                 p.list_stride);
+                 p.list_stride, (uint32_t *)(ws + p.off_big));
     }
     HIP_TRY(ctx, hipMemsetAsync(buckets, 0, (size_t)p.W * p.B * vt->el_words * 16, st));
     HIP_TRY(ctx, hipMemsetAsync(ws + p.off_queue, 0, 8, st));

@@ -15,6 +15,27 @@ enum out_form : int {
     OUT_AFFINE = 2,     // libff "special" form: (x, y, 1) or zero = (0, 1, 0)
 };
 
+// Geometry of the two-level bucket sort, shared by the launchers and the workspace planner.
+struct sort_geom {
+    int hb;               // coarse bits: bucket index = (coarse << fb) | fine
+    int fb;
+    uint32_t chunk_cap;   // entries per LDS chunk of the fine pass
+    uint32_t big_thresh;  // a coarse bin above this many entries is sorted by many workgroups
+    uint32_t big_cap;     // most such bins one call can hold (bound: total entries / big_thresh)
+    size_t big_words;     // words of scratch for them: header + list + per-bin cursors
+};
+inline sort_geom sort_geometry(size_t n, int c, int W) {
+    sort_geom g;
+    g.hb = (c - 1 < 10) ? c - 1 : 10;
+    g.fb = c - 1 - g.hb;
+    g.chunk_cap = 1024;   // about twice the expected bin size, 1K .. 16K entries
+    while (g.chunk_cap < 16384u && g.chunk_cap < 2 * (n >> g.hb)) g.chunk_cap <<= 1;
+    g.big_thresh = 16 * g.chunk_cap;
+    g.big_cap = (uint32_t)((size_t)W * n / g.big_thresh + 1);
+    g.big_words = 4 + (size_t)g.big_cap * 4 + ((size_t)g.big_cap << g.fb);
+    return g;
+}
+
 struct group_vtable {
     int curve, group;
     int fr_words;      // 32-bit words per scalar
@@ -34,10 +55,11 @@ struct group_vtable {
                     uint32_t* lists, size_t list_stride);
     // LDS-staged two-level sort (same result as count + scatter): ends[w][b] and lists[w][...].
     // coarse: W*(2^hb+1) words zeroed, cursor: W*2^hb words, digits/tmp_payload/tmp_key/lists:
-    // W*stride words each (digits may alias lists); hb = min(10, c-1); needs c <= 23
+    // W*stride words each (digits may alias lists); big: sort_geometry().big_words words, the
+    // first 4 zeroed (oversized coarse bins, sorted cooperatively); needs c <= 22
     void (*sort)(hipStream_t, const uint32_t* scalars, size_t n, int mont, int c, int W, uint32_t* coarse,
                  uint32_t* cursor, int32_t* digits, uint32_t* tmp_payload, uint32_t* tmp_key, uint32_t* ends,
-                 uint32_t* lists, size_t stride);
+                 uint32_t* lists, size_t stride, uint32_t* big);
     // segmented bucket sums: lane t of window w owns list entries [t*S, (t+1)*S); buckets[]
     // must be zero-filled; part_first / part_last: W*T points, cont_bucket: W*T words;
     // long_queue: 2 + 2*(W*T/24 + 1) words, word 0 zeroed (queue of buckets spanning many lanes)

@@ -467,7 +467,8 @@ __global__ void __launch_bounds__(SORT_TPB) k_sort_coarse(const int32_t* __restr
 __global__ void __launch_bounds__(SORT_TPB) k_sort_fine(const uint32_t* __restrict__ tmp_payload,
                                                         const uint32_t* __restrict__ tmp_key,
                                                         const uint32_t* __restrict__ coarse, size_t stride, int c, int hb,
-                                                        uint32_t chunk_cap, uint32_t* __restrict__ ends,
+                                                        uint32_t chunk_cap, uint32_t big_thresh, uint32_t big_cap,
+                                                        uint32_t* __restrict__ big, uint32_t* __restrict__ ends,
                                                         uint32_t* __restrict__ lists) {
     // dynamic LDS: 4 arrays of nfine words, chunk_cap payload words, chunk_cap fine keys (u16)
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -488,6 +489,21 @@ __global__ void __launch_bounds__(SORT_TPB) k_sort_fine(const uint32_t* __restri
     const uint32_t* pay = tmp_payload + (size_t)w * stride + b0;
     uint32_t* out = lists + (size_t)w * stride + b0;
     uint32_t* e = ends + (((size_t)w << (c - 1)) + ((size_t)bin << fb));
+    if (m > big_thresh) {
+        // oversized bin (many equal or clustered scalars): leave it to the cooperative kernels
+        // below; its bucket counts are gathered in ends[] first, so clear them
+        for (uint32_t j = threadIdx.x; j < nfine; j += SORT_TPB) e[j] = 0;
+        if (threadIdx.x == 0) {
+            const uint32_t tiles = (m + SORT_TILE - 1) / SORT_TILE;
+            const uint32_t slot = atomicAdd(&big[0], 1u);   // < big_cap: sum of m over such bins <= W * n
+            uint32_t* rec = big + 4 + 4 * (size_t)slot;
+            rec[0] = w;
+            rec[1] = bin;
+            rec[2] = atomicAdd(&big[1], tiles);
+            rec[3] = tiles;
+        }
+        return;
+    }
     // pass A: sizes of the fine buckets of this bin -> ends[]
     for (uint32_t j = threadIdx.x; j < nfine; j += SORT_TPB) chist[j] = 0;
     __syncthreads();
@@ -519,6 +535,137 @@ __global__ void __launch_bounds__(SORT_TPB) k_sort_fine(const uint32_t* __restri
         }
         __syncthreads();
         for (uint32_t j = threadIdx.x; j < nfine; j += SORT_TPB) fstart[j] += chist[j];
+        __syncthreads();
+    }
+}
+
+// Oversized coarse bins (k_sort_fine registered them in big[]: word 0 = bins, word 1 = tiles,
+// then records {w, bin, first tile, tiles}, then one cursor row of 2^fb words per record).
+// Tiles of SORT_TILE entries are spread over the whole grid: histogram by fine key with one
+// global atomic per (tile, key), a scan per bin, then an LDS counting sort per tile that
+// reserves its runs with one global atomic per (tile, key) -- the coarse pass again, one
+// level down.  With no such bin all three kernels return at once.
+struct big_tile {
+    uint32_t rec, w, bin, k0, cm;   // record, window, coarse bin, first entry within the bin, entries
+};
+AMDMSM_DEV bool big_find_tile(const uint32_t* __restrict__ big, const uint32_t* __restrict__ coarse, uint32_t nbin,
+                              uint32_t tile, uint32_t* sh, big_tile& bt, uint32_t& b0) {
+    const uint32_t nbig = big[0];
+    __syncthreads();
+    for (uint32_t r = threadIdx.x; r < nbig; r += SORT_TPB) {
+        const uint32_t* rec = big + 4 + 4 * (size_t)r;
+        if (tile >= rec[2] && tile < rec[2] + rec[3]) sh[0] = r;
+    }
+    __syncthreads();
+    bt.rec = sh[0];
+    const uint32_t* rec = big + 4 + 4 * (size_t)bt.rec;
+    bt.w = rec[0];
+    bt.bin = rec[1];
+    const uint32_t* cs = coarse + (size_t)bt.w * (nbin + 1);
+    b0 = cs[bt.bin];
+    const uint32_t m = cs[bt.bin + 1] - b0;
+    bt.k0 = (tile - rec[2]) * SORT_TILE;
+    bt.cm = (m - bt.k0 < (uint32_t)SORT_TILE) ? m - bt.k0 : (uint32_t)SORT_TILE;
+    return true;
+}
+
+__global__ void __launch_bounds__(SORT_TPB) k_sort_big_hist(const uint32_t* __restrict__ tmp_key,
+                                                            const uint32_t* __restrict__ coarse, size_t stride, int c,
+                                                            int hb, const uint32_t* __restrict__ big,
+                                                            uint32_t* __restrict__ ends) {
+    __shared__ uint32_t hist[1 << SORT_MAX_FB], sh[1];
+    const uint32_t nbin = 1u << hb;
+    const int fb = c - 1 - hb;
+    const uint32_t nfine = 1u << fb, fmask = nfine - 1u;
+    const uint32_t tiles = big[1];
+    for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        big_tile bt;
+        uint32_t b0;
+        big_find_tile(big, coarse, nbin, tile, sh, bt, b0);
+        for (uint32_t j = threadIdx.x; j < nfine; j += SORT_TPB) hist[j] = 0;
+        __syncthreads();
+        const uint32_t* key = tmp_key + (size_t)bt.w * stride + b0 + bt.k0;
+        for (uint32_t k = threadIdx.x; k < bt.cm; k += SORT_TPB) atomicAdd(&hist[key[k] & fmask], 1u);
+        __syncthreads();
+        uint32_t* e = ends + (((size_t)bt.w << (c - 1)) + ((size_t)bt.bin << fb));
+        for (uint32_t j = threadIdx.x; j < nfine; j += SORT_TPB)
+            if (hist[j]) atomicAdd(&e[j], hist[j]);
+    }
+}
+
+__global__ void __launch_bounds__(SORT_TPB) k_sort_big_scan(const uint32_t* __restrict__ coarse, int c, int hb,
+                                                            uint32_t big_cap, uint32_t* __restrict__ big,
+                                                            uint32_t* __restrict__ ends) {
+    __shared__ uint32_t cnt[1 << SORT_MAX_FB], out[1 << SORT_MAX_FB], tmp[SORT_TPB / 64 + 1];
+    const uint32_t nbin = 1u << hb;
+    const int fb = c - 1 - hb;
+    const uint32_t nfine = 1u << fb;
+    const uint32_t nbig = big[0];
+    for (uint32_t r = blockIdx.x; r < nbig; r += gridDim.x) {
+        const uint32_t* rec = big + 4 + 4 * (size_t)r;
+        const uint32_t w = rec[0], bin = rec[1];
+        const uint32_t b0 = coarse[(size_t)w * (nbin + 1) + bin];
+        uint32_t* e = ends + (((size_t)w << (c - 1)) + ((size_t)bin << fb));
+        uint32_t* cur = big + 4 + 4 * (size_t)big_cap + ((size_t)r << fb);
+        __syncthreads();
+        for (uint32_t j = threadIdx.x; j < nfine; j += SORT_TPB) cnt[j] = e[j];
+        __syncthreads();
+        block_exclusive_scan(cnt, out, nfine, tmp);
+        for (uint32_t j = threadIdx.x; j < nfine; j += SORT_TPB) {
+            cur[j] = b0 + out[j];
+            e[j] = b0 + out[j] + cnt[j];
+        }
+    }
+}
+
+__global__ void __launch_bounds__(SORT_TPB) k_sort_big_scatter(const uint32_t* __restrict__ tmp_payload,
+                                                               const uint32_t* __restrict__ tmp_key,
+                                                               const uint32_t* __restrict__ coarse, size_t stride, int c,
+                                                               int hb, uint32_t big_cap, uint32_t* __restrict__ big,
+                                                               uint32_t* __restrict__ lists) {
+    // dynamic LDS: hist / lstart / lcur / gbase of 2^fb words, SORT_TILE payloads, SORT_TILE fine keys (u16)
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    __shared__ uint32_t tmp[SORT_TPB / 64 + 1], sh[1];
+    const uint32_t nbin = 1u << hb;
+    const int fb = c - 1 - hb;
+    const uint32_t nfine = 1u << fb, fmask = nfine - 1u;
+    uint32_t* hist = smem;
+    uint32_t* lstart = hist + nfine;
+    uint32_t* lcur = lstart + nfine;
+    uint32_t* gbase = lcur + nfine;
+    uint32_t* st_payload = gbase + nfine;
+    unsigned short* st_fine = reinterpret_cast<unsigned short*>(st_payload + SORT_TILE);
+    const uint32_t tiles = big[1];
+    for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        big_tile bt;
+        uint32_t b0;
+        big_find_tile(big, coarse, nbin, tile, sh, bt, b0);
+        for (uint32_t j = threadIdx.x; j < nfine; j += SORT_TPB) hist[j] = 0;
+        __syncthreads();
+        const uint32_t* key = tmp_key + (size_t)bt.w * stride + b0 + bt.k0;
+        const uint32_t* pay = tmp_payload + (size_t)bt.w * stride + b0 + bt.k0;
+        for (uint32_t k = threadIdx.x; k < bt.cm; k += SORT_TPB) atomicAdd(&hist[key[k] & fmask], 1u);
+        __syncthreads();
+        block_exclusive_scan(hist, lstart, nfine, tmp);
+        uint32_t* cur = big + 4 + 4 * (size_t)big_cap + ((size_t)bt.rec << fb);
+        for (uint32_t j = threadIdx.x; j < nfine; j += SORT_TPB) {
+            const uint32_t h = hist[j];
+            lcur[j] = lstart[j];
+            gbase[j] = h ? atomicAdd(&cur[j], h) : 0u;
+        }
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < bt.cm; k += SORT_TPB) {
+            const uint32_t f = key[k] & fmask;
+            const uint32_t r = atomicAdd(&lcur[f], 1u);
+            st_payload[r] = pay[k];
+            st_fine[r] = (unsigned short)f;
+        }
+        __syncthreads();
+        uint32_t* out = lists + (size_t)bt.w * stride;
+        for (uint32_t k = threadIdx.x; k < bt.cm; k += SORT_TPB) {
+            const uint32_t f = st_fine[k];
+            out[gbase[f] + (k - lstart[f])] = st_payload[k];
+        }
         __syncthreads();
     }
 }
@@ -636,7 +783,43 @@ __global__ void __launch_bounds__(64) k_accumulate_fixup(const uint32_t* __restr
     store_xyzz(buckets + (w * B + b) * ZZW, acc);
 }
 
-// one wave per queued bucket: lanes stride over its partials, XOR butterfly, lane 0 stores
+// A bucket that spans thousands of lanes (one scalar value repeated across much of the input)
+// would leave its queue entry's wave with a long serial sum.  Beforehand, every aligned block
+// of FIX_BLOCK lanes that lies wholly inside one such span is folded by a wave of its own into
+// the block's first part_first slot; the closing wave then reads one partial per block.
+constexpr uint32_t FIX_BLOCK = 256;
+
+__global__ void __launch_bounds__(64) k_accumulate_compact(const uint32_t* __restrict__ ends,
+                                                           uint32_t* __restrict__ part_first, int W, uint32_t B,
+                                                           uint32_t S, uint32_t T) {
+    const uint32_t nblk = T / FIX_BLOCK;
+    if (nblk < 2) return;
+    const size_t w = blockIdx.x / (nblk - 1);
+    const uint32_t k = blockIdx.x % (nblk - 1) + 1;   // block 0 has no lane before it
+    if (w >= (size_t)W) return;
+    const uint32_t* e = ends + w * B;
+    const uint32_t total = e[B - 1];
+    const uint32_t first = k * FIX_BLOCK, last = first + FIX_BLOCK - 1;
+    const uint64_t ent_a = (uint64_t)first * S - 1, ent_b = (uint64_t)last * S;
+    if (ent_b >= total) return;
+    // the bucket of the last entry before the block still runs in the block's last lane
+    if (bucket_of_entry(e, B, (uint32_t)ent_a) != bucket_of_entry(e, B, (uint32_t)ent_b)) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    Xyzz<E> acc, x;
+    xyzz_set_inf(acc);
+    for (uint32_t u = first + lane; u <= last; u += 64) {
+        load_xyzz(x, part_first + (w * T + u) * ZZW);
+        xyzz_add(acc, acc, x);
+    }
+    Jac<E> j;
+    xyzz_to_jac(j, acc);
+    wave_group_sum(j, 64);
+    jac_to_xyzz(acc, j);
+    if (lane == 0) store_xyzz(part_first + (w * T + first) * ZZW, acc);
+}
+
+// one wave per queued bucket: lanes stride over its partials (one per folded block, see
+// k_accumulate_compact), XOR butterfly, lane 0 stores
 __global__ void __launch_bounds__(64) k_accumulate_fixup_long(const uint32_t* __restrict__ ends,
                                                               const uint32_t* __restrict__ part_first,
                                                               const uint32_t* __restrict__ part_last,
@@ -654,7 +837,14 @@ __global__ void __launch_bounds__(64) k_accumulate_fixup_long(const uint32_t* __
         const uint32_t t_last = (ends[w * B + b] - 1) / S;
         Xyzz<E> acc, x;
         if (lane == 0) load_xyzz(acc, part_last + g * ZZW); else xyzz_set_inf(acc);
-        for (uint32_t u = t + 1 + lane; u <= t_last; u += 64) {
+        // lanes t+1 .. t_last = head [t+1, h), nb folded blocks from h, tail [tail0, t_last]
+        uint32_t h = (t + 1 + FIX_BLOCK - 1) / FIX_BLOCK * FIX_BLOCK;
+        uint32_t nb = 0;
+        if (h <= t_last + 1) nb = (t_last + 1 - h) / FIX_BLOCK; else h = t_last + 1;
+        const uint32_t nh = h - (t + 1), tail0 = h + nb * FIX_BLOCK;
+        const uint32_t items = nh + nb + (t_last + 1 - tail0);
+        for (uint32_t i = lane; i < items; i += 64) {
+            const uint32_t u = i < nh ? t + 1 + i : (i < nh + nb ? h + (i - nh) * FIX_BLOCK : tail0 + (i - nh - nb));
             load_xyzz(x, part_first + (w * T + u) * ZZW);
             xyzz_add(acc, acc, x);
         }
@@ -1215,9 +1405,10 @@ void l_scatter(hipStream_t st, const uint32_t* scalars, size_t n, int mont, int 
 // digits / lists may alias (digits are dead once k_sort_coarse has run)
 void l_sort(hipStream_t st, const uint32_t* scalars, size_t n, int mont, int c, int W, uint32_t* coarse,
             uint32_t* cursor, int32_t* digits, uint32_t* tmp_payload, uint32_t* tmp_key, uint32_t* ends, uint32_t* lists,
-            size_t stride) {
+            size_t stride, uint32_t* big) {
     if (!n) return;
-    const int hb = (c - 1 < SORT_MAX_HB) ? c - 1 : SORT_MAX_HB;
+    const sort_geom sg = sort_geometry(n, c, W);
+    const int hb = sg.hb;
     const uint32_t nbin = 1u << hb;
     // scalars per k_sort_digits workgroup: enough workgroups for every CU, few enough global atomics
     uint32_t per_block = 8192;
@@ -1227,12 +1418,14 @@ void l_sort(hipStream_t st, const uint32_t* scalars, size_t n, int mont, int c, 
     hipLaunchKernelGGL(k_sort_scan, dim3(W), dim3(SORT_TPB), 0, st, coarse, cursor, nbin);
     hipLaunchKernelGGL(k_sort_coarse, dim3((unsigned)((n + SORT_TILE - 1) / SORT_TILE), W), dim3(SORT_TPB), 0, st, digits, n,
                        stride, c, hb, cursor, tmp_payload, tmp_key);
-    // chunk capacity of k_sort_fine: about twice the expected bin size, 1K .. 16K entries
-    uint32_t chunk_cap = 1024;
-    while (chunk_cap < (uint32_t)SORT_CHUNK && chunk_cap < 2 * (n >> hb)) chunk_cap <<= 1;
-    const size_t fine_lds = ((size_t)4 << (c - 1 - hb)) * 4 + (size_t)chunk_cap * 6;
+    const size_t fine_lds = ((size_t)4 << sg.fb) * 4 + (size_t)sg.chunk_cap * 6;
     hipLaunchKernelGGL(k_sort_fine, dim3(nbin, W), dim3(SORT_TPB), fine_lds, st, tmp_payload, tmp_key, coarse, stride, c, hb,
-                       chunk_cap, ends, lists);
+                       sg.chunk_cap, sg.big_thresh, sg.big_cap, big, ends, lists);
+    hipLaunchKernelGGL(k_sort_big_hist, dim3(2048), dim3(SORT_TPB), 0, st, tmp_key, coarse, stride, c, hb, big, ends);
+    hipLaunchKernelGGL(k_sort_big_scan, dim3(256), dim3(SORT_TPB), 0, st, coarse, c, hb, sg.big_cap, big, ends);
+    const size_t big_lds = ((size_t)4 << sg.fb) * 4 + (size_t)SORT_TILE * 6;
+    hipLaunchKernelGGL(k_sort_big_scatter, dim3(2048), dim3(SORT_TPB), big_lds, st, tmp_payload, tmp_key, coarse, stride, c,
+                       hb, sg.big_cap, big, lists);
 }
 void l_accumulate(hipStream_t st, const uint32_t* ends, const uint32_t* lists, size_t list_stride, const uint32_t* bases,
                   uint32_t* buckets, uint32_t* part_first, uint32_t* part_last, uint32_t* cont_bucket,
@@ -1242,6 +1435,9 @@ void l_accumulate(hipStream_t st, const uint32_t* ends, const uint32_t* lists, s
     hipLaunchKernelGGL(k_accumulate, dim3(blocks_for((size_t)W * T)), dim3(TPB), 0, st, ends, lists, list_stride, bases,
                        buckets, part_first, part_last, cont_bucket, W, B, S, T);
     if (after_main) (void)hipEventRecord(after_main, st);
+    if (T / FIX_BLOCK >= 2)
+        hipLaunchKernelGGL(k_accumulate_compact, dim3((unsigned)(W * (T / FIX_BLOCK - 1))), dim3(64), 0, st, ends,
+                           part_first, W, B, S, T);
     hipLaunchKernelGGL(k_accumulate_fixup, dim3(blocks_for((size_t)W * T, 64)), dim3(64), 0, st, ends, part_first,
                        part_last, cont_bucket, buckets, long_queue, W, B, S, T);
     const size_t max_long = (size_t)W * T / LONG_SPAN + 1;

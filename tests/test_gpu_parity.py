@@ -260,6 +260,24 @@ def test_skewed_scalars(engine, port, name, curve, group):
     assert (engine.multi_exp(curve, group, bases, same, base_form=multi_exp_base_form_special) == want).all()
 
 
+def test_heavy_hitter_buckets_large(engine, port):
+    """2^18 points where 70% of the scalars (then all of them) are one repeated value: every
+    window has one coarse sort bin far above the cooperative-sort threshold and one bucket
+    spanning thousands of accumulation lanes (folded block-wise before the closing wave)."""
+    curve, group, n = 0, 1, 1 << 18
+    rng = np.random.default_rng(11)
+    sc = port.scalars_sha512(curve, 777, n)
+    sc[rng.random(n) < 0.7] = sc[1]
+    bases = engine.gen_bases_seq(curve, group, n, first=5)
+    want = port.multi_exp(curve, group, bases, sc, port.BDLO12_SIGNED, 1, chunks=8, omp=True)
+    for c in (0, 11):
+        got = engine.multi_exp(curve, group, bases, sc, base_form=multi_exp_base_form_special, window_bits=c)
+        assert (got == want).all(), c
+    same = np.repeat(sc[1:2], n, axis=0)
+    want = port.multi_exp(curve, group, bases, same, port.BDLO12_SIGNED, 1, chunks=8, omp=True)
+    assert (engine.multi_exp(curve, group, bases, same, base_form=multi_exp_base_form_special) == want).all()
+
+
 def _be_bytes(limbs_le):
     """uint64 LE limb array -> big-endian byte string (object_write_to_buffer, ffi_serialization.tcc:117-136)."""
     return np.frombuffer(np.ascontiguousarray(limbs_le, dtype=np.uint64).tobytes()[::-1], dtype=np.uint8)

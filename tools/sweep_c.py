@@ -18,6 +18,8 @@ def main():
     ap.add_argument("--log2n", type=int, nargs="+", default=[20])
     ap.add_argument("--c", type=int, nargs="+", default=[0])
     ap.add_argument("--segment-len", type=int, default=0)
+    ap.add_argument("--repeat-frac", type=float, default=0.0,
+                    help="fraction of the scalars replaced by ONE repeated random value (heavy-hitter buckets)")
     args = ap.parse_args()
     curve, group = CURVES[args.curve], args.group
     dev = torch.device("cuda", 0)
@@ -30,6 +32,10 @@ def main():
         bases = torch.empty((n, sz["affine_bytes"] // 8), dtype=torch.int64, device=dev)
         eng.gen_bases_seq_device(curve, group, 0, n, bases.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
         scalars = random_scalars(curve, n, dev, seed=99)
+        if args.repeat_frac > 0:
+            k = int(n * args.repeat_frac)
+            idx = torch.randperm(n, device=dev)[:k]
+            scalars[idx] = scalars[0].clone()
         torch.cuda.synchronize()
         for c in args.c:
             p = libff_amd.plan(curve, group, n, c)
