@@ -137,6 +137,25 @@ int amdmsm_multi_exp_stream_file(amdmsm_ctx *ctx, int curve, int group, const ch
                                  size_t offset_bytes, const void *scalars, size_t n,
                                  size_t chunk_points, void *out_xyz, const amdmsm_opts *opts);
 
+/* Streaming MSM over precomputed multiples.  Replaces multi_exp_stream_with_precompute<
+ * form_montgomery, compression_off, G, Fr> (multiexp_stream.hpp:29-42, multiexp_stream.tcc:
+ * 193-223): the stream holds, for every base P, the amdmsm_precompute_num_digits(curve, c)
+ * records P, [2^c]P, [2^2c]P, ... (what create_precompute_file_for_config writes,
+ * profile_multiexp.cpp:120-150); digit j of a scalar selects the bucket for record j, all in
+ * ONE set of 2^(c-1) buckets, and no doublings are needed.  As in the reference, a carry out of
+ * the last digit is dropped.  chunk_points = 0 picks about 2^20 records per chunk. */
+size_t amdmsm_precompute_num_digits(int curve, size_t c);   /* (Fr::num_bits + c - 1) / c */
+int amdmsm_multi_exp_stream_with_precompute(amdmsm_ctx *ctx, int curve, int group,
+                                            amdmsm_read_fn read, void *read_ctx,
+                                            const void *scalars, size_t n, size_t precompute_c,
+                                            size_t chunk_points, void *out_xyz,
+                                            const amdmsm_opts *opts);
+int amdmsm_multi_exp_stream_with_precompute_file(amdmsm_ctx *ctx, int curve, int group,
+                                                 const char *path, size_t offset_bytes,
+                                                 const void *scalars, size_t n,
+                                                 size_t precompute_c, size_t chunk_points,
+                                                 void *out_xyz, const amdmsm_opts *opts);
+
 /* Fixed-base batch exponentiation: out[i] = scalars[i] * g (or (coeff * scalars[i]) * g when
  * coeff != NULL), i < n, through a window table built on the device.  Replaces
  * get_window_table + batch_exp / batch_exp_with_coeff (multiexp.hpp:99-134,
@@ -154,6 +173,18 @@ int amdmsm_export_affine_device(amdmsm_ctx *ctx, int curve, int group, const voi
                                 size_t n, void *d_dst_xyz, void *stream);
 int amdmsm_msm_device(amdmsm_ctx *ctx, int curve, int group, const void *d_bases_affine,
                       const void *d_scalars, size_t n, void *d_out_xyz, const amdmsm_opts *opts);
+/* The same with the table resident in HBM (288 GB hold [2^(jc)]P for 2^26 alt_bn128 G1 bases):
+ * amdmsm_precompute_bases_device fills d_table[i * num_digits + j] = [2^(j*c)] P_i (compact
+ * affine, n * num_digits records) from compact affine bases -- the device-side
+ * create_precompute_file_for_config -- and amdmsm_msm_precomputed_device is
+ * multi_exp_precompute_from_fifo (multiexp_stream.tcc:124-162) on it.  num_digits =
+ * amdmsm_precompute_num_digits() reproduces the reference; one more digit where
+ * c divides Fr::num_bits keeps the final carry. */
+int amdmsm_precompute_bases_device(amdmsm_ctx *ctx, int curve, int group, const void *d_bases_affine,
+                                   size_t n, size_t c, size_t num_digits, void *d_table, void *stream);
+int amdmsm_msm_precomputed_device(amdmsm_ctx *ctx, int curve, int group, const void *d_table,
+                                  const void *d_scalars, size_t n, size_t c, size_t num_digits,
+                                  void *d_out_xyz, const amdmsm_opts *opts);
 /* sum of k engine-Jacobian partial results (multi-GPU / chunk combination, multiexp.tcc:681-687) */
 int amdmsm_sum_points_device(amdmsm_ctx *ctx, int curve, int group, const void *d_points_jacobian,
                              int k, int out_form, void *d_out_xyz, void *stream);

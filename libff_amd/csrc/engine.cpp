@@ -87,6 +87,7 @@ size_t libff_log2(size_t n) {
 
 struct plan_t {
     int c = 0, W = 0;
+    int D = 0;   // > 0: precomputed-table mode, D digits per scalar in one bucket set (W == 1)
     uint32_t B = 0, L = 0;
     uint32_t S = 0, T = 0;   // entries per accumulation lane, lanes per window
     size_t off_counts = 0, off_lists = 0, off_buckets = 0, off_lvl0 = 0, off_lvl1 = 0, total = 0;
@@ -120,11 +121,15 @@ int choose_c(const group_vtable *vt, size_t n) {
     return best_c;
 }
 
-int make_plan(const group_vtable *vt, size_t n, int c_req, int L_req, plan_t &p, int S_req = 0) {
+// table_digits > 0: every scalar contributes table_digits entries (one per digit, pointing at
+// its precomputed multiple) to a single bucket set; n is then the number of ENTRIES.
+int make_plan(const group_vtable *vt, size_t n, int c_req, int L_req, plan_t &p, int S_req = 0, int table_digits = 0) {
     if (c_req < 0 || c_req > 24 || c_req == 1) return AMDMSM_ERR_BAD_ARG;
+    if (table_digits && (c_req < 2 || c_req > 22)) return AMDMSM_ERR_BAD_ARG;
     p.c = c_req ? c_req : choose_c(vt, n);
     // field_get_signed_digit needs room for bits + 2 (multiexp.tcc:584-586)
-    p.W = (vt->fr_bits + 2 + p.c - 1) / p.c;
+    p.W = table_digits ? 1 : (vt->fr_bits + 2 + p.c - 1) / p.c;
+    p.D = table_digits;
     p.B = (uint32_t)1 << (p.c - 1);
     // buckets per reduction lane: longer segments amortise the per-segment scalar multiple and
     // wave fold (~40 vs ~70 field products per bucket at L = 32 vs 8) once there are enough
@@ -214,12 +219,15 @@ void record(amdmsm_ctx *ctx, ws_slot &sl, int idx, hipStream_t st) {
 }
 
 // The whole single-GPU MSM on device-resident inputs.
+// table_digits > 0: d_bases is a precompute_table with that many multiples per scalar
+// (multi_exp_precompute_from_fifo, multiexp_stream.tcc:124-162: one bucket set, no doublings).
 int msm_device_impl(amdmsm_ctx *ctx, const group_vtable *vt, const uint32_t *d_bases, const uint32_t *d_scalars,
-                    size_t n, uint32_t *d_out, const amdmsm_opts *opts) {
+                    size_t n, uint32_t *d_out, const amdmsm_opts *opts, int table_digits = 0) {
     hipStream_t st = (opts && opts->stream) ? (hipStream_t)opts->stream : ctx->stream;
     const int form = opts ? opts->out_form : AMDMSM_OUT_LIBFF;
     const int mont = (opts && opts->scalars_plain) ? 0 : 1;
-    if (n >= ((size_t)1 << 31)) return fail(ctx, AMDMSM_ERR_TOO_LARGE, "n must be < 2^31 per call");
+    const size_t entries = table_digits ? n * (size_t)table_digits : n;   // per sorted list
+    if (entries >= ((size_t)1 << 31)) return fail(ctx, AMDMSM_ERR_TOO_LARGE, "n (times table digits) must be < 2^31 per call");
     if (n == 0) {
         // empty sum = zero; sum_points over 0 points writes G::zero() in the requested form
         vt->sum_points(st, d_out, 0, form, d_out);
@@ -229,7 +237,7 @@ int msm_device_impl(amdmsm_ctx *ctx, const group_vtable *vt, const uint32_t *d_b
     plan_t p;
     // tuning knobs for experiments: AMDMSM_ACC_S (entries per accumulation lane)
     static const int acc_s_env = getenv("AMDMSM_ACC_S") ? atoi(getenv("AMDMSM_ACC_S")) : 0;
-    int rc = make_plan(vt, n, opts ? opts->window_bits : 0, opts ? opts->segment_len : 0, p, acc_s_env);
+    int rc = make_plan(vt, entries, opts ? opts->window_bits : 0, opts ? opts->segment_len : 0, p, acc_s_env, table_digits);
     if (rc) return fail(ctx, rc, "bad window_bits / segment_len");
     const int slot_idx = (int)(ctx->next++ % (unsigned)ctx->depth);
     ws_slot &sl = ctx->slots[slot_idx];
@@ -246,7 +254,7 @@ int msm_device_impl(amdmsm_ctx *ctx, const group_vtable *vt, const uint32_t *d_b
 
     record(ctx, sl, 0, st);
     static const bool atomic_sort = getenv("AMDMSM_SORT") && !strcmp(getenv("AMDMSM_SORT"), "atomic");
-    if (atomic_sort || p.c > 22) {
+    if ((atomic_sort || p.c > 22) && !table_digits) {
         HIP_TRY(ctx, hipMemsetAsync(counts, 0, (size_t)p.W * p.B * 4, st));
         vt->count(st, d_scalars, n, mont, p.c, p.W, counts);
         record(ctx, sl, 1, st);
@@ -255,9 +263,10 @@ int msm_device_impl(amdmsm_ctx *ctx, const group_vtable *vt, const uint32_t *d_b
         HIP_TRY(ctx, hipMemsetAsync(ws + p.off_coarse, 0, (size_t)p.W * 1025 * 4, st));
         HIP_TRY(ctx, hipMemsetAsync(ws + p.off_big, 0, 16, st));
         record(ctx, sl, 1, st);
-        vt->sort(st, d_scalars, n, mont, p.c, p.W, (uint32_t *)(ws + p.off_coarse), (uint32_t *)(ws + p.off_cursor),
-                 (int32_t *)lists, (uint32_t *)(ws + p.off_tmp_payload), (uint32_t *)(ws + p.off_tmp_key), counts, lists,
-                 p.list_stride, (uint32_t *)(ws + p.off_big));
+        vt->sort(st, d_scalars, n, mont, p.c, table_digits ? table_digits : p.W, (uint32_t *)(ws + p.off_coarse),
+                 (uint32_t *)(ws + p.off_cursor), (int32_t *)lists, (uint32_t *)(ws + p.off_tmp_payload),
+                 (uint32_t *)(ws + p.off_tmp_key), counts, lists, p.list_stride, (uint32_t *)(ws + p.off_big),
+                 table_digits ? 1 : 0);
     }
     HIP_TRY(ctx, hipMemsetAsync(buckets, 0, (size_t)p.W * p.B * vt->el_words * 16, st));
     HIP_TRY(ctx, hipMemsetAsync(ws + p.off_queue, 0, 8, st));
@@ -444,6 +453,49 @@ int amdmsm_msm_device(amdmsm_ctx *ctx, int curve, int group, const void *d_bases
     if (!d_out_xyz || (n && (!d_bases_affine || !d_scalars))) return fail(ctx, AMDMSM_ERR_BAD_ARG, "null pointer");
     return msm_device_impl(ctx, vt, (const uint32_t *)d_bases_affine, (const uint32_t *)d_scalars, n,
                            (uint32_t *)d_out_xyz, opts);
+}
+
+size_t amdmsm_precompute_num_digits(int curve, size_t c) {
+    // multiexp_stream.tcc:205, profile_multiexp.cpp:126: (FieldT::num_bits + c - 1) / c
+    const group_vtable *vt = find_vt(curve, AMDMSM_G1);
+    if (!vt || c == 0) return 0;
+    return ((size_t)vt->fr_bits + c - 1) / c;
+}
+
+int amdmsm_precompute_bases_device(amdmsm_ctx *ctx, int curve, int group, const void *d_bases_affine, size_t n,
+                                   size_t c, size_t num_digits, void *d_table, void *stream) {
+    GET_VT(ctx, curve, group);
+    if (c < 2 || c > 22 || num_digits < 1 || num_digits > 512) return fail(ctx, AMDMSM_ERR_BAD_ARG, "c / num_digits");
+    if (n && (!d_bases_affine || !d_table)) return fail(ctx, AMDMSM_ERR_BAD_ARG, "null pointer");
+    if (!n) return AMDMSM_OK;
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    const size_t aff_bytes = (size_t)vt->el_words * 8;
+    const size_t chunk = std::min(n, (size_t)1 << 18);
+    void *tmp = nullptr;
+    HIP_TRY(ctx, hipMalloc(&tmp, chunk * num_digits * aff_bytes));
+    for (size_t lo = 0; lo < n; lo += chunk) {
+        const size_t cnt = std::min(chunk, n - lo);
+        vt->precompute_table(st, (const uint32_t *)((const char *)d_bases_affine + lo * aff_bytes), cnt, (int)c,
+                             (int)num_digits, (uint32_t *)tmp, (uint32_t *)((char *)d_table + lo * num_digits * aff_bytes));
+    }
+    const hipError_t e1 = hipGetLastError(), e2 = hipStreamSynchronize(st);
+    (void)hipFree(tmp);
+    HIP_TRY(ctx, e1);
+    HIP_TRY(ctx, e2);
+    return AMDMSM_OK;
+}
+
+int amdmsm_msm_precomputed_device(amdmsm_ctx *ctx, int curve, int group, const void *d_table, const void *d_scalars,
+                                  size_t n, size_t c, size_t num_digits, void *d_out_xyz, const amdmsm_opts *opts) {
+    GET_VT(ctx, curve, group);
+    if (!d_out_xyz || (n && (!d_table || !d_scalars))) return fail(ctx, AMDMSM_ERR_BAD_ARG, "null pointer");
+    if (c < 2 || c > 22 || num_digits < 1 || num_digits > 512) return fail(ctx, AMDMSM_ERR_BAD_ARG, "c / num_digits");
+    amdmsm_opts o = {};
+    if (opts) o = *opts;
+    else o.out_form = AMDMSM_OUT_LIBFF;
+    o.window_bits = (int)c;
+    return msm_device_impl(ctx, vt, (const uint32_t *)d_table, (const uint32_t *)d_scalars, n, (uint32_t *)d_out_xyz, &o,
+                           (int)num_digits);
 }
 
 int amdmsm_import_bases_device(amdmsm_ctx *ctx, int curve, int group, const void *d_src_xyz, size_t stride_bytes,
@@ -650,21 +702,27 @@ int amdmsm_multi_exp_filter_one_zero(amdmsm_ctx *ctx, int curve, int group, cons
     return amdmsm_multi_exp(ctx, curve, group, bases_xyz, base_stride_bytes, base_form, scalars, n, out_xyz, opts);
 }
 
+}   // extern "C"
+
+namespace {
 // multi_exp_stream (multiexp_stream.hpp:25-33, multiexp_stream.tcc:164-191): the bases arrive
 // through a reader in libff's on-disk format and never have to be resident at once.  Chunks of
 // `chunk_points` records are read into pinned staging buffers, copied and decoded on the
 // device, and reduced to one partial point each on alternating streams / workspace slots, so
 // reading chunk k+1 overlaps the MSM of chunk k; the partials are summed at the end
 // (multiexp.tcc:681-687).
-int amdmsm_multi_exp_stream(amdmsm_ctx *ctx, int curve, int group, amdmsm_read_fn read, void *read_ctx,
-                            const void *scalars, size_t n, size_t chunk_points, void *out_xyz,
-                            const amdmsm_opts *opts) {
+// recs = records per scalar in the stream: 1 for multi_exp_stream; for the precompute variant the
+// num_digits multiples [2^(jc)]P of each base, consumed with window size precompute_c
+// (element_buffers_from_stream_producer, multiexp_stream.tcc:33-49).
+int stream_impl(amdmsm_ctx *ctx, int curve, int group, amdmsm_read_fn read, void *read_ctx, const void *scalars,
+                size_t n, size_t chunk_points, void *out_xyz, const amdmsm_opts *opts, size_t recs,
+                size_t precompute_c) {
     if (!ctx || !read || !out_xyz || (n && !scalars)) return AMDMSM_ERR_BAD_ARG;
     const group_vtable *vt = find_vt(curve, group);
     if (!vt) return fail(ctx, AMDMSM_ERR_UNSUPPORTED, "unknown curve/group");
-    const size_t xyz_bytes = (size_t)vt->el_words * 12, aff_bytes = (size_t)vt->el_words * 8;
+    const size_t xyz_bytes = (size_t)vt->el_words * 12, aff_bytes = (size_t)vt->el_words * 8 * recs;
     const size_t fr_bytes = (size_t)vt->fr_words * 4;
-    if (chunk_points == 0) chunk_points = (size_t)1 << 20;
+    if (chunk_points == 0) chunk_points = std::max<size_t>(((size_t)1 << 20) / recs, 1024);
     if (chunk_points > n && n) chunk_points = n;
     const size_t nchunks = n ? (n + chunk_points - 1) / chunk_points : 0;
     constexpr int NB = 2;
@@ -732,9 +790,13 @@ int amdmsm_multi_exp_stream(amdmsm_ctx *ctx, int curve, int group, amdmsm_read_f
         TRY_S(hipMemcpyAsync(d_raw[b], h_stage[b], want, hipMemcpyHostToDevice, streams[b]));
         TRY_S(hipMemcpyAsync(d_sc[b], (const char *)scalars + lo * fr_bytes, cnt * fr_bytes, hipMemcpyHostToDevice,
                              streams[b]));
-        vt->disk_decode(streams[b], (const uint32_t *)d_raw[b], cnt, (uint32_t *)d_aff[b]);
+        vt->disk_decode(streams[b], (const uint32_t *)d_raw[b], cnt * recs, (uint32_t *)d_aff[b]);
         o.stream = streams[b];
-        rc = amdmsm_msm_device(ctx, curve, group, d_aff[b], d_sc[b], cnt, (char *)d_partials + k * xyz_bytes, &o);
+        if (precompute_c)
+            rc = amdmsm_msm_precomputed_device(ctx, curve, group, d_aff[b], d_sc[b], cnt, precompute_c, recs,
+                                               (char *)d_partials + k * xyz_bytes, &o);
+        else
+            rc = amdmsm_msm_device(ctx, curve, group, d_aff[b], d_sc[b], cnt, (char *)d_partials + k * xyz_bytes, &o);
         if (rc) {
             cleanup();
             return rc;
@@ -753,13 +815,11 @@ int amdmsm_multi_exp_stream(amdmsm_ctx *ctx, int curve, int group, amdmsm_read_f
 #undef TRY_S
 }
 
-namespace {
 size_t file_reader(void *fp, void *dst, size_t bytes) { return fread(dst, 1, bytes, (FILE *)fp); }
-}  // namespace
 
-int amdmsm_multi_exp_stream_file(amdmsm_ctx *ctx, int curve, int group, const char *path, size_t offset_bytes,
-                                 const void *scalars, size_t n, size_t chunk_points, void *out_xyz,
-                                 const amdmsm_opts *opts) {
+int stream_file_impl(amdmsm_ctx *ctx, int curve, int group, const char *path, size_t offset_bytes, const void *scalars,
+                     size_t n, size_t chunk_points, void *out_xyz, const amdmsm_opts *opts, size_t recs,
+                     size_t precompute_c) {
     if (!ctx || !path) return AMDMSM_ERR_BAD_ARG;
     FILE *fp = fopen(path, "rb");
     if (!fp) return fail(ctx, AMDMSM_ERR_BAD_ARG, std::string("cannot open ") + path);
@@ -767,9 +827,50 @@ int amdmsm_multi_exp_stream_file(amdmsm_ctx *ctx, int curve, int group, const ch
         fclose(fp);
         return fail(ctx, AMDMSM_ERR_BAD_ARG, "seek failed");
     }
-    const int rc = amdmsm_multi_exp_stream(ctx, curve, group, file_reader, fp, scalars, n, chunk_points, out_xyz, opts);
+    const int rc = stream_impl(ctx, curve, group, file_reader, fp, scalars, n, chunk_points, out_xyz, opts, recs,
+                               precompute_c);
     fclose(fp);
     return rc;
+}
+}  // namespace
+
+extern "C" {
+
+int amdmsm_multi_exp_stream(amdmsm_ctx *ctx, int curve, int group, amdmsm_read_fn read, void *read_ctx,
+                            const void *scalars, size_t n, size_t chunk_points, void *out_xyz,
+                            const amdmsm_opts *opts) {
+    return stream_impl(ctx, curve, group, read, read_ctx, scalars, n, chunk_points, out_xyz, opts, 1, 0);
+}
+
+int amdmsm_multi_exp_stream_file(amdmsm_ctx *ctx, int curve, int group, const char *path, size_t offset_bytes,
+                                 const void *scalars, size_t n, size_t chunk_points, void *out_xyz,
+                                 const amdmsm_opts *opts) {
+    return stream_file_impl(ctx, curve, group, path, offset_bytes, scalars, n, chunk_points, out_xyz, opts, 1, 0);
+}
+
+// multi_exp_stream_with_precompute (multiexp_stream.hpp:29-42, multiexp_stream.tcc:193-223): the
+// stream holds, per base, the num_digits = ceil(Fr::num_bits / c) multiples [2^(jc)]P; every
+// (scalar digit, multiple) pair lands in ONE bucket set and no doublings are needed.  Like the
+// reference, a carry out of the last digit is dropped (it cannot occur when the top digit has
+// spare bits, e.g. the 254-bit alt_bn128 Fr with c = 16).
+int amdmsm_multi_exp_stream_with_precompute(amdmsm_ctx *ctx, int curve, int group, amdmsm_read_fn read, void *read_ctx,
+                                            const void *scalars, size_t n, size_t precompute_c, size_t chunk_points,
+                                            void *out_xyz, const amdmsm_opts *opts) {
+    const size_t recs = amdmsm_precompute_num_digits(curve, precompute_c);
+    if (!ctx) return AMDMSM_ERR_BAD_ARG;
+    if (precompute_c < 2 || precompute_c > 22 || !recs) return fail(ctx, AMDMSM_ERR_BAD_ARG, "precompute_c must be 2..22");
+    return stream_impl(ctx, curve, group, read, read_ctx, scalars, n, chunk_points, out_xyz, opts, recs, precompute_c);
+}
+
+int amdmsm_multi_exp_stream_with_precompute_file(amdmsm_ctx *ctx, int curve, int group, const char *path,
+                                                 size_t offset_bytes, const void *scalars, size_t n,
+                                                 size_t precompute_c, size_t chunk_points, void *out_xyz,
+                                                 const amdmsm_opts *opts) {
+    const size_t recs = amdmsm_precompute_num_digits(curve, precompute_c);
+    if (!ctx) return AMDMSM_ERR_BAD_ARG;
+    if (precompute_c < 2 || precompute_c > 22 || !recs) return fail(ctx, AMDMSM_ERR_BAD_ARG, "precompute_c must be 2..22");
+    return stream_file_impl(ctx, curve, group, path, offset_bytes, scalars, n, chunk_points, out_xyz, opts, recs,
+                            precompute_c);
 }
 
 int amdmsm_batch_exp(amdmsm_ctx *ctx, int curve, int group, size_t scalar_size, size_t window, const void *g_xyz,

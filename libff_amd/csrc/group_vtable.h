@@ -48,6 +48,9 @@ struct group_vtable {
     // form_special != 0 promises Z == 1 or zero (multi_exp_base_form_special).
     void (*import_bases)(hipStream_t, const uint32_t* src, size_t stride_words, int form_special,
                          size_t n, uint32_t* dst_affine);
+    // table[i*D + j] = [2^(j*c)] P_i (compact affine), j < D; tmp: n*D affine-sized slots of scratch
+    void (*precompute_table)(hipStream_t, const uint32_t* bases_affine, size_t n, int c, int D, uint32_t* tmp,
+                             uint32_t* table);
     // histogram of signed radix-2^c digits: counts[w * B + (|d| - 1)]++
     void (*count)(hipStream_t, const uint32_t* scalars, size_t n, int mont, int c, int W, uint32_t* counts);
     // cursor[] holds exclusive bucket starts on entry, bucket ends on exit
@@ -59,7 +62,10 @@ struct group_vtable {
     // first 4 zeroed (oversized coarse bins, sorted cooperatively); needs c <= 22
     void (*sort)(hipStream_t, const uint32_t* scalars, size_t n, int mont, int c, int W, uint32_t* coarse,
                  uint32_t* cursor, int32_t* digits, uint32_t* tmp_payload, uint32_t* tmp_key, uint32_t* ends,
-                 uint32_t* lists, size_t stride, uint32_t* big);
+                 uint32_t* lists, size_t stride, uint32_t* big, int flat);
+    // flat != 0: the W digits of scalar i become entries i*W .. i*W+W-1 of ONE list over one
+    // bucket set (their payload indexes a precompute_table); then stride >= n*W, coarse / cursor /
+    // ends are those of a single window and big is sized by sort_geometry(n*W, c, 1)
     // segmented bucket sums: lane t of window w owns list entries [t*S, (t+1)*S); buckets[]
     // must be zero-filled; part_first / part_last: W*T points, cont_bucket: W*T words;
     // long_queue: 2 + 2*(W*T/24 + 1) words, word 0 zeroed (queue of buckets spanning many lanes)

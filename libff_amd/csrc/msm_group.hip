@@ -373,11 +373,14 @@ AMDMSM_DEV uint32_t block_exclusive_scan(const uint32_t* cnt, uint32_t* out, uin
 
 __global__ void __launch_bounds__(SORT_TPB) k_sort_digits(const uint32_t* __restrict__ scalars, size_t n, int mont, int c,
                                                           int W, int hb, uint32_t per_block, int32_t* __restrict__ digits,
-                                                          size_t stride, uint32_t* __restrict__ coarse_counts) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];   // [W][2^hb]
+                                                          size_t stride, uint32_t* __restrict__ coarse_counts, int flat) {
+    // flat: the W digits of scalar i are entries i*W .. i*W+W-1 of ONE list (they index a table
+    // of precomputed multiples [2^(jc)]P_i and share a single bucket set)
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];   // [W][2^hb]   (flat: [2^hb])
     const uint32_t nbin = 1u << hb;
     const int fb = c - 1 - hb;
-    for (uint32_t j = threadIdx.x; j < (uint32_t)W * nbin; j += SORT_TPB) smem[j] = 0;
+    const uint32_t nctr = flat ? nbin : (uint32_t)W * nbin;
+    for (uint32_t j = threadIdx.x; j < nctr; j += SORT_TPB) smem[j] = 0;
     __syncthreads();
     const size_t base = (size_t)blockIdx.x * per_block;
     for (uint32_t k = threadIdx.x; k < per_block; k += SORT_TPB) {
@@ -386,15 +389,15 @@ __global__ void __launch_bounds__(SORT_TPB) k_sort_digits(const uint32_t* __rest
         uint32_t s[FRW];
         load_scalar(s, scalars, i, mont);
         for_each_signed_digit(s, c, W, [&](int w, int32_t d) {
-            digits[(size_t)w * stride + i] = d;
+            digits[flat ? i * (size_t)W + w : (size_t)w * stride + i] = d;
             if (d != 0) {
                 const uint32_t idx = (uint32_t)(d < 0 ? -d : d) - 1u;
-                atomicAdd(&smem[(uint32_t)w * nbin + (idx >> fb)], 1u);
+                atomicAdd(&smem[(flat ? 0u : (uint32_t)w * nbin) + (idx >> fb)], 1u);
             }
         });
     }
     __syncthreads();
-    for (uint32_t j = threadIdx.x; j < (uint32_t)W * nbin; j += SORT_TPB) {
+    for (uint32_t j = threadIdx.x; j < nctr; j += SORT_TPB) {
         const uint32_t v = smem[j];
         if (v) atomicAdd(&coarse_counts[(j / nbin) * (nbin + 1) + (j % nbin)], v);
     }
@@ -1025,6 +1028,58 @@ __global__ void __launch_bounds__(TPB) k_export_affine(const uint32_t* __restric
     store_jac(dst + i * XYZW, p);
 }
 
+// Table of precomputed multiples for the single-bucket-set MSM (what profile_multiexp.cpp:120-150
+// writes to disk for multi_exp_stream_with_precompute): table[i*D + j] = [2^(j*c)] P_i, affine.
+// One lane walks one base through (D-1)*c doublings; (X, Y) are parked in the table slots and
+// (Z, prefix product of the Z's) in tmp, then one inversion per lane turns all D entries affine.
+__global__ void __launch_bounds__(TPB) k_precompute_table(const uint32_t* __restrict__ bases, size_t n, int c, int D,
+                                                          uint32_t* __restrict__ tmp, uint32_t* __restrict__ table) {
+    const size_t i = gtid();
+    if (i >= n) return;
+    Aff<E> a;
+    load_aff(a, bases + i * AFFW);
+    uint32_t* row = table + i * (size_t)D * AFFW;
+    uint32_t* trow = tmp + i * (size_t)D * AFFW;   // per entry: Z, prefix
+    store_aff(row, a);
+    Jac<E> cur;
+    jac_from_aff(cur, a);
+    E acc;
+    el_one(acc);
+    int last = 0;   // entries 1 .. last are finite (an infinite base or a point of even order stops early)
+    for (int j = 1; j < D; ++j) {
+        for (int k = 0; k < c; ++k) jac_dbl(cur, cur);
+        if (jac_is_inf(cur)) break;
+        el_store(row + (size_t)j * AFFW, cur.x);
+        el_store(row + (size_t)j * AFFW + EW, cur.y);
+        el_store(trow + (size_t)j * AFFW, cur.z);
+        el_store(trow + (size_t)j * AFFW + EW, acc);
+        el_mul(acc, acc, cur.z);
+        last = j;
+    }
+    E inv;
+    el_inv(inv, acc);
+    for (int j = D - 1; j >= 1; --j) {
+        Aff<E> o;
+        if (j > last) {
+            el_zero(o.x);
+            el_zero(o.y);
+        } else {
+            E z, pre, zi, z2, x, y;
+            el_load(z, trow + (size_t)j * AFFW);
+            el_load(pre, trow + (size_t)j * AFFW + EW);
+            el_load(x, row + (size_t)j * AFFW);
+            el_load(y, row + (size_t)j * AFFW + EW);
+            el_mul(zi, inv, pre);   // Z_j^-1
+            el_mul(inv, inv, z);
+            el_sqr(z2, zi);
+            el_mul(o.x, x, z2);
+            el_mul(z2, z2, zi);
+            el_mul(o.y, y, z2);
+        }
+        store_aff(row + (size_t)j * AFFW, o);
+    }
+}
+
 AMDMSM_DEV void load_generator(Jac<E>& g) {
     el_set_words(g.x, GP::GEN_X);
     el_set_words(g.y, GP::GEN_Y);
@@ -1392,6 +1447,10 @@ void l_import_bases(hipStream_t st, const uint32_t* src, size_t stride_words, in
     const size_t lanes = form_special ? n : (n + IMPORT_K - 1) / IMPORT_K;
     hipLaunchKernelGGL(k_import_bases, dim3(blocks_for(lanes)), dim3(TPB), 0, st, src, stride_words, form_special, n, dst);
 }
+void l_precompute_table(hipStream_t st, const uint32_t* bases, size_t n, int c, int D, uint32_t* tmp, uint32_t* table) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_precompute_table, dim3(blocks_for(n)), dim3(TPB), 0, st, bases, n, c, D, tmp, table);
+}
 void l_count(hipStream_t st, const uint32_t* scalars, size_t n, int mont, int c, int W, uint32_t* counts) {
     if (!n) return;
     hipLaunchKernelGGL(k_count, dim3(blocks_for(n)), dim3(TPB), 0, st, scalars, n, mont, c, W, counts);
@@ -1405,21 +1464,24 @@ void l_scatter(hipStream_t st, const uint32_t* scalars, size_t n, int mont, int 
 // digits / lists may alias (digits are dead once k_sort_coarse has run)
 void l_sort(hipStream_t st, const uint32_t* scalars, size_t n, int mont, int c, int W, uint32_t* coarse,
             uint32_t* cursor, int32_t* digits, uint32_t* tmp_payload, uint32_t* tmp_key, uint32_t* ends, uint32_t* lists,
-            size_t stride, uint32_t* big) {
+            size_t stride, uint32_t* big, int flat) {
     if (!n) return;
-    const sort_geom sg = sort_geometry(n, c, W);
+    // flat: one list of n*W entries (entry i*W + j = digit j of scalar i), one bucket set
+    const size_t ne = flat ? n * (size_t)W : n;
+    const int We = flat ? 1 : W;
+    const sort_geom sg = sort_geometry(ne, c, We);
     const int hb = sg.hb;
     const uint32_t nbin = 1u << hb;
     // scalars per k_sort_digits workgroup: enough workgroups for every CU, few enough global atomics
     uint32_t per_block = 8192;
     while (per_block > SORT_TPB && (n + per_block - 1) / per_block < 1024) per_block >>= 1;
     hipLaunchKernelGGL(k_sort_digits, dim3((unsigned)((n + per_block - 1) / per_block)), dim3(SORT_TPB),
-                       (size_t)W * nbin * 4, st, scalars, n, mont, c, W, hb, per_block, digits, stride, coarse);
-    hipLaunchKernelGGL(k_sort_scan, dim3(W), dim3(SORT_TPB), 0, st, coarse, cursor, nbin);
-    hipLaunchKernelGGL(k_sort_coarse, dim3((unsigned)((n + SORT_TILE - 1) / SORT_TILE), W), dim3(SORT_TPB), 0, st, digits, n,
-                       stride, c, hb, cursor, tmp_payload, tmp_key);
+                       (size_t)W * nbin * 4, st, scalars, n, mont, c, W, hb, per_block, digits, stride, coarse, flat);
+    hipLaunchKernelGGL(k_sort_scan, dim3(We), dim3(SORT_TPB), 0, st, coarse, cursor, nbin);
+    hipLaunchKernelGGL(k_sort_coarse, dim3((unsigned)((ne + SORT_TILE - 1) / SORT_TILE), We), dim3(SORT_TPB), 0, st, digits,
+                       ne, stride, c, hb, cursor, tmp_payload, tmp_key);
     const size_t fine_lds = ((size_t)4 << sg.fb) * 4 + (size_t)sg.chunk_cap * 6;
-    hipLaunchKernelGGL(k_sort_fine, dim3(nbin, W), dim3(SORT_TPB), fine_lds, st, tmp_payload, tmp_key, coarse, stride, c, hb,
+    hipLaunchKernelGGL(k_sort_fine, dim3(nbin, We), dim3(SORT_TPB), fine_lds, st, tmp_payload, tmp_key, coarse, stride, c, hb,
                        sg.chunk_cap, sg.big_thresh, sg.big_cap, big, ends, lists);
     hipLaunchKernelGGL(k_sort_big_hist, dim3(2048), dim3(SORT_TPB), 0, st, tmp_key, coarse, stride, c, hb, big, ends);
     hipLaunchKernelGGL(k_sort_big_scan, dim3(256), dim3(SORT_TPB), 0, st, coarse, c, hb, sg.big_cap, big, ends);
@@ -1533,7 +1595,7 @@ void l_madd_bench(hipStream_t st, const uint32_t* pts, uint32_t* out, size_t nth
 
 const group_vtable g_vt = {
     GP::CURVE, GP::GROUP, FRW, EW, FR::BITS, GP::LIBFF_PROJECTIVE ? 1 : 0, FR::R,
-    l_import_bases, l_count, l_scatter, l_sort, l_accumulate, l_reduce_segments, l_sum_butterfly, l_horner, l_sum_points,
+    l_import_bases, l_precompute_table, l_count, l_scatter, l_sort, l_accumulate, l_reduce_segments, l_sum_butterfly, l_horner, l_sum_points,
     l_gen_bases_seq, l_export_affine, l_ffi_decode_points, l_ffi_decode_scalars, l_ffi_encode_point, l_disk_decode, l_fixed_base_exp, l_field_op, l_group_op, l_digits, l_mul_bench, l_madd_bench,
 };
 

@@ -42,7 +42,10 @@ EXPORTED_SYMBOLS = [
     "amdmsm_device_count", "amdmsm_ctx_create", "amdmsm_ctx_destroy", "amdmsm_strerror",
     "amdmsm_last_error", "amdmsm_sizes", "amdmsm_plan", "amdmsm_pippenger_optimal_c",
     "amdmsm_bdlo12_signed_optimal_c", "amdmsm_multi_exp", "amdmsm_multi_exp_filter_one_zero",
-    "amdmsm_batch_to_special", "amdmsm_batch_exp", "amdmsm_multi_exp_stream", "amdmsm_multi_exp_stream_file", "amdmsm_import_bases_device", "amdmsm_export_affine_device",
+    "amdmsm_batch_to_special", "amdmsm_batch_exp", "amdmsm_multi_exp_stream", "amdmsm_multi_exp_stream_file",
+    "amdmsm_precompute_num_digits", "amdmsm_multi_exp_stream_with_precompute",
+    "amdmsm_multi_exp_stream_with_precompute_file", "amdmsm_precompute_bases_device",
+    "amdmsm_msm_precomputed_device", "amdmsm_import_bases_device", "amdmsm_export_affine_device",
     "amdmsm_msm_device", "amdmsm_sum_points_device", "amdmsm_gen_bases_seq_device",
     "amdmsm_set_timing", "amdmsm_get_timings", "amdmsm_set_pipeline_depth", "amdmsm_last_slot",
     "amdmsm_get_slot_timings", "amdmsm_field_op_device", "amdmsm_group_op_device",
@@ -77,6 +80,7 @@ def load_library():
         L.amdmsm_last_error.argtypes = [ctypes.c_void_p]
         L.amdmsm_pippenger_optimal_c.restype = ctypes.c_size_t
         L.amdmsm_bdlo12_signed_optimal_c.restype = ctypes.c_size_t
+        L.amdmsm_precompute_num_digits.restype = ctypes.c_size_t
         L.amdmsm_ctx_destroy.restype = None
         L.amdmsm_ctx_destroy.argtypes = [ctypes.c_void_p]
         _lib = L
@@ -86,6 +90,12 @@ def load_library():
 def bdlo12_signed_optimal_c(num_entries):
     """multiexp.hpp:53-57 / multiexp.tcc:637-641"""
     return int(load_library().amdmsm_bdlo12_signed_optimal_c(ctypes.c_size_t(num_entries)))
+
+
+def precompute_num_digits(curve, c):
+    """(Fr::num_bits + c - 1) / c: multiples per base in a precompute file (multiexp_stream.tcc:205)."""
+    lib = load_library()
+    return int(lib.amdmsm_precompute_num_digits(curve, ctypes.c_size_t(c)))
 
 
 def pippenger_optimal_c(num_elements):
@@ -112,6 +122,11 @@ def plan(curve, group, n, window_bits=0):
     return {"c": c.value, "num_windows": w.value, "num_buckets": b.value, "workspace_bytes": ws.value}
 
 
+def _vp(x):
+    """device address (int, e.g. torch's data_ptr()) or c_void_p (Engine.malloc) -> c_void_p"""
+    return x if isinstance(x, ctypes.c_void_p) else ctypes.c_void_p(x)
+
+
 def _np_ptr(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
@@ -122,7 +137,7 @@ class Engine:
     def __init__(self, device=0):
         self.lib = load_library()
         self.device = device
-        h = ctypes.c_void_p(None)
+        h = ctypes.c_void_p()
         rc = self.lib.amdmsm_ctx_create(device, ctypes.byref(h))
         if rc:
             raise AmdMsmError("amdmsm_ctx_create(device=%d) failed: %s" %
@@ -234,6 +249,48 @@ class Engine:
         self._check(rc, "amdmsm_multi_exp_stream_file")
         return out
 
+    def multi_exp_stream_with_precompute_file(self, curve, group, path, scalars, precompute_c, offset_bytes=0,
+                                              chunk_points=0, out_form=OUT_AFFINE, scalars_plain=False):
+        """libff::multi_exp_stream_with_precompute<form_montgomery, compression_off>
+        (multiexp_stream.tcc:193-223): ``path`` holds precompute_num_digits(curve, c) multiples
+        [2^(jc)]P per base, as profile_multiexp.cpp:120-150 writes them."""
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint64)
+        s = sizes(curve, group)
+        out = np.zeros(s["g_bytes"] // 8, dtype=np.uint64)
+        o = self._opts(out_form=out_form, scalars_plain=scalars_plain)
+        rc = self.lib.amdmsm_multi_exp_stream_with_precompute_file(
+            self.h, curve, group, path.encode(), ctypes.c_size_t(offset_bytes),
+            _np_ptr(scalars) if scalars.shape[0] else None, ctypes.c_size_t(scalars.shape[0]),
+            ctypes.c_size_t(precompute_c), ctypes.c_size_t(chunk_points), _np_ptr(out), ctypes.byref(o))
+        self._check(rc, "amdmsm_multi_exp_stream_with_precompute_file")
+        return out
+
+    def precompute_table(self, curve, group, bases, c, num_digits=None):
+        """Host convenience around amdmsm_precompute_bases_device: special-form (x, y, 1) records in,
+        table[i * D + j] = [2^(jc)] bases[i] out, again as special-form records."""
+        bases = np.ascontiguousarray(bases, dtype=np.uint64)
+        n = bases.shape[0]
+        D = num_digits or precompute_num_digits(curve, c)
+        s = sizes(curve, group)
+        d_src = self.malloc(max(bases.nbytes, 16))
+        d_aff = self.malloc(max(n * s["affine_bytes"], 16))
+        d_tab = self.malloc(max(n * D * s["affine_bytes"], 16))
+        d_out = self.malloc(max(n * D * s["g_bytes"], 16))
+        try:
+            self.h2d(d_src, bases)
+            self.import_bases_device(curve, group, d_src, bases.strides[0], multi_exp_base_form_special, n, d_aff)
+            self._check(self.lib.amdmsm_precompute_bases_device(
+                self.h, curve, group, _vp(d_aff), ctypes.c_size_t(n), ctypes.c_size_t(c),
+                ctypes.c_size_t(D), _vp(d_tab), None), "amdmsm_precompute_bases_device")
+            self.export_affine_device(curve, group, d_tab, n * D, d_out)
+            out = np.zeros((n * D, s["g_bytes"] // 8), dtype=np.uint64)
+            self.synchronize()
+            self.d2h(out, d_out)
+        finally:
+            for p in (d_src, d_aff, d_tab, d_out):
+                self.free(p)
+        return out
+
     def batch_exp(self, curve, group, scalar_size, window, g, v, coeff=None, scalars_plain=False):
         """libff::batch_exp / batch_exp_with_coeff (multiexp.tcc:874-947) for the table that
         get_window_table(scalar_size, window, g) would build: res[i] = (coeff *) v[i] * g."""
@@ -270,7 +327,7 @@ class Engine:
 
     # -------------------------------------------------------- raw device API
     def malloc(self, nbytes):
-        p = ctypes.c_void_p(None)
+        p = ctypes.c_void_p()
         self._check(self.lib.amdmsm_malloc(self.h, ctypes.c_size_t(nbytes), ctypes.byref(p)), "amdmsm_malloc")
         return p
 
@@ -289,32 +346,46 @@ class Engine:
         self._check(self.lib.amdmsm_synchronize(self.h), "amdmsm_synchronize")
 
     def import_bases_device(self, curve, group, d_src_xyz, stride_bytes, base_form, n, d_dst_affine, stream=None):
-        self._check(self.lib.amdmsm_import_bases_device(self.h, curve, group, ctypes.c_void_p(d_src_xyz),
+        self._check(self.lib.amdmsm_import_bases_device(self.h, curve, group, _vp(d_src_xyz),
                                                         ctypes.c_size_t(stride_bytes), base_form,
-                                                        ctypes.c_size_t(n), ctypes.c_void_p(d_dst_affine),
-                                                        ctypes.c_void_p(stream)), "amdmsm_import_bases_device")
+                                                        ctypes.c_size_t(n), _vp(d_dst_affine),
+                                                        _vp(stream)), "amdmsm_import_bases_device")
 
     def export_affine_device(self, curve, group, d_src_affine, n, d_dst_xyz, stream=None):
-        self._check(self.lib.amdmsm_export_affine_device(self.h, curve, group, ctypes.c_void_p(d_src_affine),
-                                                         ctypes.c_size_t(n), ctypes.c_void_p(d_dst_xyz),
-                                                         ctypes.c_void_p(stream)), "amdmsm_export_affine_device")
+        self._check(self.lib.amdmsm_export_affine_device(self.h, curve, group, _vp(d_src_affine),
+                                                         ctypes.c_size_t(n), _vp(d_dst_xyz),
+                                                         _vp(stream)), "amdmsm_export_affine_device")
 
     def msm_device(self, curve, group, d_bases_affine, d_scalars, n, d_out_xyz, out_form=OUT_LIBFF,
                    window_bits=0, segment_len=0, scalars_plain=False, stream=None):
         o = self._opts(window_bits, segment_len, out_form, scalars_plain, stream)
-        self._check(self.lib.amdmsm_msm_device(self.h, curve, group, ctypes.c_void_p(d_bases_affine),
-                                               ctypes.c_void_p(d_scalars), ctypes.c_size_t(n),
-                                               ctypes.c_void_p(d_out_xyz), ctypes.byref(o)), "amdmsm_msm_device")
+        self._check(self.lib.amdmsm_msm_device(self.h, curve, group, _vp(d_bases_affine),
+                                               _vp(d_scalars), ctypes.c_size_t(n),
+                                               _vp(d_out_xyz), ctypes.byref(o)), "amdmsm_msm_device")
+
+    def precompute_bases_device(self, curve, group, d_bases_affine, n, c, num_digits, d_table, stream=None):
+        self._check(self.lib.amdmsm_precompute_bases_device(
+            self.h, curve, group, _vp(d_bases_affine), ctypes.c_size_t(n), ctypes.c_size_t(c),
+            ctypes.c_size_t(num_digits), _vp(d_table), _vp(stream)),
+            "amdmsm_precompute_bases_device")
+
+    def msm_precomputed_device(self, curve, group, d_table, d_scalars, n, c, num_digits, d_out_xyz,
+                               out_form=OUT_LIBFF, segment_len=0, scalars_plain=False, stream=None):
+        o = self._opts(0, segment_len, out_form, scalars_plain, stream)
+        self._check(self.lib.amdmsm_msm_precomputed_device(
+            self.h, curve, group, _vp(d_table), _vp(d_scalars), ctypes.c_size_t(n),
+            ctypes.c_size_t(c), ctypes.c_size_t(num_digits), _vp(d_out_xyz), ctypes.byref(o)),
+            "amdmsm_msm_precomputed_device")
 
     def sum_points_device(self, curve, group, d_points, k, out_form, d_out, stream=None):
-        self._check(self.lib.amdmsm_sum_points_device(self.h, curve, group, ctypes.c_void_p(d_points), k, out_form,
-                                                      ctypes.c_void_p(d_out), ctypes.c_void_p(stream)),
+        self._check(self.lib.amdmsm_sum_points_device(self.h, curve, group, _vp(d_points), k, out_form,
+                                                      _vp(d_out), _vp(stream)),
                     "amdmsm_sum_points_device")
 
     def gen_bases_seq_device(self, curve, group, first, n, d_dst_affine, stream=None):
         self._check(self.lib.amdmsm_gen_bases_seq_device(self.h, curve, group, ctypes.c_uint64(first),
-                                                         ctypes.c_size_t(n), ctypes.c_void_p(d_dst_affine),
-                                                         ctypes.c_void_p(stream)), "amdmsm_gen_bases_seq_device")
+                                                         ctypes.c_size_t(n), _vp(d_dst_affine),
+                                                         _vp(stream)), "amdmsm_gen_bases_seq_device")
 
     def set_timing(self, enable=True):
         self._check(self.lib.amdmsm_set_timing(self.h, int(enable)), "amdmsm_set_timing")

@@ -1266,6 +1266,87 @@ int orc_disk_write(int curve, int group, size_t n, const uint64_t *elems, uint8_
     return 0;
 }
 
+/* ------------------------------------------------- precomputed multiples */
+/* entries_per_base_element, profile_multiexp.cpp:126 == num_digits, multiexp_stream.tcc:205 */
+size_t orc_precompute_num_digits(int curve, size_t c)
+{
+    const orc_group *g = find_group(curve, 1);
+    if (!g || !c) return 0;
+    return (g->fr->bits + c - 1) / c;
+}
+
+/* create_precompute_file_for_config, profile_multiexp.cpp:120-150, before serialisation: for
+ * every base el the D records el, [2^c]el, [2^2c]el, ... (returned in affine form, which is
+ * what group_write stores). */
+int orc_precompute_table(int curve, int group, size_t n, const uint64_t *bases, size_t cc, size_t D, uint64_t *out)
+{
+    const orc_group *g = find_group(curve, group);
+    if (!g) return -2;
+    ctx_t c = mkctx(g);
+    const int gl = GLIMBS(&c);
+    for (size_t i = 0; i < n; ++i) {
+        uint64_t el[MAXG];
+        g_cpy(&c, el, bases + i * gl);
+        g_to_affine(&c, out + (i * D) * gl, el);
+        for (size_t k = 1; k < D; ++k) {
+            for (size_t j = 0; j < cc; ++j) g_dbl(&c, el, el);
+            g_to_affine(&c, out + (i * D + k) * gl, el);
+        }
+    }
+    return 0;
+}
+
+/* multi_exp_stream_with_precompute -> multi_exp_precompute_from_fifo, multiexp_stream.tcc:
+ * 124-162, 193-223: D = (num_bits + c - 1)/c signed digits per exponent (field_get_signed_digits,
+ * field_utils.tcc:205-239: a carry out of digit D-1 is dropped), digit k of exponent i adds
+ * table[i*D + k] (special form, mixed addition) to ONE set of 2^(c-1) buckets, summed by
+ * multiexp_accumulate_buckets. */
+int orc_multi_exp_precompute(int curve, int group, size_t n, const uint64_t *table, const uint64_t *scalars, size_t cc,
+                             size_t D, uint64_t *out_affine)
+{
+    const orc_group *g = find_group(curve, group);
+    if (!g) return -2;
+    mx_t m = {mkctx(g), g->fr, ORC_FORM_SPECIAL};
+    const ctx_t *c = &m.c;
+    const int gl = GLIMBS(c), rn = m.fr->n;
+    const size_t num_buckets = (size_t)1 << (cc - 1);
+    uint64_t *buckets = (uint64_t *)malloc(num_buckets * (size_t)gl * 8);
+    unsigned char *hit = (unsigned char *)calloc(num_buckets, 1);
+    uint64_t bi[MAXN], nb[MAXG], res[MAXG];
+    int any = 0;
+    for (size_t i = 0; i < n; ++i) {
+        fp_from_mont(m.fr, bi, scalars + i * rn);
+        for (size_t k = 0; k < D; ++k) {
+            const long digit = get_signed_digit(bi, rn, cc, k);
+            if (digit == 0) continue;
+            const uint64_t *p = table + (i * D + k) * gl;
+            size_t idx;
+            if (digit < 0) {
+                idx = (size_t)(-digit) - 1;
+                g_neg(c, nb, p);
+                p = nb;
+            } else {
+                idx = (size_t)digit - 1;
+            }
+            if (hit[idx]) {
+                bucket_add(&m, buckets + idx * gl, p);
+            } else {
+                g_cpy(c, buckets + idx * gl, p);
+                hit[idx] = 1;
+            }
+            any = 1;
+        }
+    }
+    /* with no bucket hit the reference's multiexp_accumulate_buckets walks off the array;
+     * the defined answer for "nothing to add" is zero */
+    if (any) accumulate_buckets(c, buckets, hit, num_buckets, res);
+    else g_zero(c, res);
+    g_to_affine(c, out_affine, res);
+    free(hit);
+    free(buckets);
+    return 0;
+}
+
 /* ------------------------------------------------------------ FFI codecs */
 /* object_write_to_buffer / field_serializer, ffi_serialization.tcc:19-136:
  * big-endian plain bigint, extension coefficients highest-order first. */

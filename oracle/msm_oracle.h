@@ -69,6 +69,13 @@ int orc_batch_exp(int curve, int group, size_t scalar_size, size_t window, const
 /* n elements -> libff's binary / Montgomery / uncompressed records (2 * coord bytes each) */
 int orc_disk_write(int curve, int group, size_t n, const uint64_t *elems, uint8_t *out);
 
+/* precomputed multiples [2^(kc)]P (profile_multiexp.cpp:120-150) and the single-bucket-set MSM
+ * over them (multi_exp_stream_with_precompute, multiexp_stream.tcc:124-162, 193-223) */
+size_t orc_precompute_num_digits(int curve, size_t c);
+int orc_precompute_table(int curve, int group, size_t n, const uint64_t *bases, size_t c, size_t D, uint64_t *out);
+int orc_multi_exp_precompute(int curve, int group, size_t n, const uint64_t *table, const uint64_t *scalars, size_t c,
+                             size_t D, uint64_t *out_affine);
+
 size_t orc_log2(size_t n);
 size_t orc_pippenger_optimal_c(size_t n);
 size_t orc_bdlo12_signed_optimal_c(size_t n);

@@ -175,6 +175,34 @@ def batch_exp(curve, group, scalar_size, window, g, v, coeff=None):
     return out
 
 
+def precompute_num_digits(curve, c):
+    lib().orc_precompute_num_digits.restype = ctypes.c_size_t
+    return int(lib().orc_precompute_num_digits(curve, ctypes.c_size_t(c)))
+
+
+def precompute_table(curve, group, bases, c, num_digits=None):
+    """D multiples [2^(kc)]P per base, affine records (profile_multiexp.cpp:120-150)."""
+    bases = _u64(bases)
+    n = bases.shape[0]
+    D = num_digits or precompute_num_digits(curve, c)
+    out = np.zeros((n * D, bases.shape[1]), dtype=np.uint64)
+    assert lib().orc_precompute_table(curve, group, ctypes.c_size_t(n), _p(bases), ctypes.c_size_t(c),
+                                      ctypes.c_size_t(D), _p(out)) == 0
+    return out
+
+
+def multi_exp_precompute(curve, group, table, scalars, c, num_digits=None):
+    """multi_exp_stream_with_precompute (multiexp_stream.tcc:193-223) on an in-memory table."""
+    table, scalars = _u64(table), _u64(scalars)
+    n = scalars.shape[0]
+    D = num_digits or precompute_num_digits(curve, c)
+    assert table.shape[0] == n * D
+    out = np.zeros(sizes(curve, group)["g_bytes"] // 8, dtype=np.uint64)
+    assert lib().orc_multi_exp_precompute(curve, group, ctypes.c_size_t(n), _p(table), _p(scalars), ctypes.c_size_t(c),
+                                          ctypes.c_size_t(D), _p(out)) == 0
+    return out
+
+
 def disk_write(curve, group, elems):
     """libff on-disk records (binary, Montgomery, uncompressed) of the given elements, as bytes"""
     s = sizes(curve, group)

@@ -193,6 +193,27 @@ def disk_write(curve, group, elems):
     return out
 
 
+def precompute_table(curve, group, bases, c, num_digits):
+    bases = np.ascontiguousarray(bases, dtype=np.uint64)
+    n = bases.shape[0]
+    out = np.zeros((n * num_digits, bases.shape[1]), dtype=np.uint64)
+    assert lib().ref_precompute_table(curve, group, ctypes.c_size_t(n), _p(bases), ctypes.c_size_t(c),
+                                      ctypes.c_size_t(num_digits), _p(out)) == 0
+    return out
+
+
+def multi_exp_stream_with_precompute(curve, group, disk_bytes, scalars, c):
+    """The reference's multi_exp_stream_with_precompute<form_montgomery, compression_off> on an
+    in-memory copy of a precompute file."""
+    disk_bytes = np.ascontiguousarray(disk_bytes, dtype=np.uint8)
+    scalars = np.ascontiguousarray(scalars, dtype=np.uint64)
+    out = np.zeros(sizes(curve, group)["g_bytes"] // 8, dtype=np.uint64)
+    assert lib().ref_multi_exp_stream_with_precompute(
+        curve, group, ctypes.c_size_t(scalars.shape[0]), _p(disk_bytes), ctypes.c_size_t(disk_bytes.size),
+        _p(scalars), ctypes.c_size_t(c), _p(out)) == 0
+    return out
+
+
 def multi_exp_stream(curve, group, disk_bytes, scalars):
     s = sizes(curve, group)
     disk_bytes = np.ascontiguousarray(disk_bytes, dtype=np.uint8)

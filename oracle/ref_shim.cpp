@@ -281,6 +281,37 @@ template<typename G, typename Fr> struct ops {
         return 0;
     }
 
+    // the multiples a precompute file holds (profile_multiexp.cpp:120-150), as in-memory records
+    static int precompute_table(size_t n, const void *elems, size_t c, size_t D, void *out)
+    {
+        const G *e = (const G *)elems;
+        G *o = (G *)out;
+        for (size_t i = 0; i < n; ++i) {
+            G el;
+            memcpy((void *)&el, (const void *)&e[i], sizeof(G));
+            for (size_t k = 0; k < D; ++k) {
+                if (k) {
+                    for (size_t j = 0; j < c; ++j) el = el.dbl();
+                }
+                G a = el;
+                a.to_affine_coordinates();
+                memcpy((void *)&o[i * D + k], (const void *)&a, sizeof(G));
+            }
+        }
+        return 0;
+    }
+    static int stream_precompute_c(
+        size_t n, const void *bytes, size_t nbytes, const void *scalars, size_t c, void *out_affine)
+    {
+        std::istringstream is(std::string((const char *)bytes, nbytes), std::ios_base::in | std::ios_base::binary);
+        std::vector<Fr> s(n);
+        memcpy((void *)s.data(), scalars, n * sizeof(Fr));
+        G r = multi_exp_stream_with_precompute<form_montgomery, compression_off, G, Fr>(is, s, c);
+        r.to_affine_coordinates();
+        memcpy(out_affine, (const void *)&r, sizeof(G));
+        return 0;
+    }
+
     // get_window_table + batch_exp / batch_exp_with_coeff (multiexp.tcc:809-947)
     static int batch_exp_c(
         size_t scalar_size, size_t window, const void *g_in, size_t n, const void *scalars, const void *coeff, void *out)
@@ -512,6 +543,21 @@ int ref_multi_exp_stream(
 {
     int rc = 0;
     DISPATCH(curve, group, rc = O::stream_c(n, bytes, nbytes, scalars, out_affine));
+    return rc;
+}
+
+int ref_precompute_table(int curve, int group, size_t n, const void *elems, size_t c, size_t D, void *out)
+{
+    int rc = 0;
+    DISPATCH(curve, group, rc = O::precompute_table(n, elems, c, D, out));
+    return rc;
+}
+
+int ref_multi_exp_stream_with_precompute(
+    int curve, int group, size_t n, const void *bytes, size_t nbytes, const void *scalars, size_t c, void *out_affine)
+{
+    int rc = 0;
+    DISPATCH(curve, group, rc = O::stream_precompute_c(n, bytes, nbytes, scalars, c, out_affine));
     return rc;
 }
 

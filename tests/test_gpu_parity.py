@@ -423,3 +423,63 @@ def test_multi_exp_stream_from_file(engine, port, name, curve, group, tmp_path):
     tp.write_bytes(g[f"{name}/disk_bytes"].tobytes()[:-5])
     with pytest.raises(libff_amd.AmdMsmError):
         engine.multi_exp_stream_file(curve, group, str(tp), sc6)
+
+
+@pytest.mark.parametrize("name,curve,group", GROUPS)
+def test_precomputed_multiples_msm(engine, port, name, curve, group, tmp_path):
+    """multi_exp_stream_with_precompute (multiexp_stream.tcc:193-223): the device-built table of
+    [2^(kc)]P equals the oracle's, the golden results of the reference (including the window
+    size that loses the last carry) come out of the file entry point, and the HBM-resident
+    entry points agree."""
+    g, lit = golden(), literal()["groups"][name]
+    nb = 24
+    bases = port.bases_r32(curve, group, nb)
+    bases_z = bases.copy()
+    sc = port.scalars_sha512(curve, 70, nb)
+    for c in lit["precompute_c"]:
+        D = libff_amd.precompute_num_digits(curve, c)
+        assert D == port.precompute_num_digits(curve, c)
+        tab = engine.precompute_table(curve, group, bases, c)
+        assert (tab == port.precompute_table(curve, group, bases, c)).all()
+        assert (tab[D:2 * D] == g[f"{name}/pre_c{c}_table_base1"]).all()
+        path = tmp_path / f"{name}_{c}.bin"
+        path.write_bytes(port.disk_write(curve, group, tab).tobytes())
+        for chunk in (0, 7):
+            got = engine.multi_exp_stream_with_precompute_file(curve, group, str(path), sc, c, chunk_points=chunk)
+            assert (got == g[f"{name}/pre_c{c}_msm"]).all(), (c, chunk)
+    # larger, ragged, with a zero base; safe digit count (carry kept) == plain multi_exp
+    n = 2500 if group == 1 and curve != 2 else 600
+    c = 9
+    bases = port.bases_seq(curve, group, n, first=21)
+    bases[11] = port.group_consts(curve, group)[1]
+    sc = port.scalars_sha512(curve, 808, n)
+    D = libff_amd.precompute_num_digits(curve, c)
+    tab = engine.precompute_table(curve, group, bases, c)
+    want = port.multi_exp_precompute(curve, group, tab, sc, c)
+    path = tmp_path / f"{name}_big.bin"
+    path.write_bytes(port.disk_write(curve, group, tab).tobytes())
+    for chunk in (0, 1000):
+        got = engine.multi_exp_stream_with_precompute_file(curve, group, str(path), sc, c, chunk_points=chunk)
+        assert (got == want).all(), chunk
+    tab1 = engine.precompute_table(curve, group, bases, c, num_digits=D + 1)
+    full = port.multi_exp(curve, group, bases, sc, port.BDLO12_SIGNED, 1, chunks=4, omp=True)
+    p1 = tmp_path / f"{name}_big1.bin"
+    p1.write_bytes(port.disk_write(curve, group, tab1).tobytes())
+    s = libff_amd.sizes(curve, group)
+    # HBM-resident entry points on the D+1 table
+    d_tab = engine.malloc(tab1.shape[0] * s["affine_bytes"])
+    d_src = engine.malloc(tab1.nbytes)
+    d_sc = engine.malloc(sc.nbytes)
+    d_out = engine.malloc(s["g_bytes"])
+    try:
+        engine.h2d(d_src, tab1)
+        engine.h2d(d_sc, sc)
+        engine.import_bases_device(curve, group, d_src, tab1.strides[0], multi_exp_base_form_special, tab1.shape[0], d_tab)
+        engine.msm_precomputed_device(curve, group, d_tab, d_sc, n, c, D + 1, d_out, out_form=libff_amd.OUT_AFFINE)
+        engine.synchronize()
+        out = np.zeros(s["g_bytes"] // 8, dtype=np.uint64)
+        engine.d2h(out, d_out)
+    finally:
+        for p in (d_tab, d_src, d_sc, d_out):
+            engine.free(p)
+    assert (out == full).all()

@@ -189,6 +189,35 @@ def test_batch_exp(port, name, curve, group):
 
 
 @pytest.mark.parametrize("name,curve,group", GROUPS)
+def test_precomputed_multiples_msm(port, name, curve, group):
+    """multi_exp_stream_with_precompute (multiexp_stream.tcc:193-223) as the reference computed
+    it from a precompute file (profile_multiexp.cpp:120-150) of 24 R32 bases -- including a
+    window size dividing Fr::num_bits, where the reference drops the last carry and the answer
+    is NOT the plain multi_exp."""
+    g, lit = golden(), literal()["groups"][name]
+    nb = 24
+    bases = port.bases_r32(curve, group, nb)
+    sc = port.scalars_sha512(curve, 70, nb)
+    full = port.multi_exp(curve, group, bases, sc)
+    bits = lit["fr_bits"]
+    differs = 0
+    for c in lit["precompute_c"]:
+        D = port.precompute_num_digits(curve, c)
+        assert D == (bits + c - 1) // c
+        tab = port.precompute_table(curve, group, bases, c)
+        assert (tab[D:2 * D] == g[f"{name}/pre_c{c}_table_base1"]).all()
+        got = port.multi_exp_precompute(curve, group, tab, sc, c)
+        assert (got == g[f"{name}/pre_c{c}_msm"]).all(), c
+        differs += int(not (got == full).all())
+        if bits % c:   # spare bits in the top digit: no carry can be lost
+            assert (got == full).all()
+        # one more digit keeps the carry: always the true sum
+        tab1 = port.precompute_table(curve, group, bases, c, num_digits=D + 1)
+        assert (port.multi_exp_precompute(curve, group, tab1, sc, c, num_digits=D + 1) == full).all()
+    assert differs >= 1   # 24 random scalars: at least one loses its carry when c | num_bits
+
+
+@pytest.mark.parametrize("name,curve,group", GROUPS)
 def test_on_disk_base_records(port, name, curve, group):
     """group_write<encoding_binary, form_montgomery, compression_off> byte layout and
     multi_exp_stream over it (multiexp_stream.tcc:164-191)."""

@@ -68,6 +68,23 @@ def test_disk_format_and_stream(port, ref, name, curve, group):
 
 
 @pytest.mark.parametrize("name,curve,group", GROUPS)
+def test_precompute_table_and_msm(port, ref, name, curve, group):
+    """[2^(kc)]P tables and multi_exp_stream_with_precompute, restatement vs the reference, with a
+    zero base and a non-affine base in the input."""
+    n, c = 40, 7
+    bits = ref.sizes(curve, group)["fr_bits"]
+    D = (bits + c - 1) // c
+    b = ref.bases_seq(curve, group, n, first=9)
+    b[4] = ref.group_consts(curve, group)[1]
+    b[6] = ref.group_op(curve, group, 2, b[6])
+    sc = ref.scalars_sha512(curve, 300, n)
+    tab = ref.precompute_table(curve, group, b, c, D)
+    assert (port.precompute_table(curve, group, b, c) == tab).all()
+    want = ref.multi_exp_stream_with_precompute(curve, group, ref.disk_write(curve, group, tab), sc, c)
+    assert (port.multi_exp_precompute(curve, group, tab, sc, c) == want).all()
+
+
+@pytest.mark.parametrize("name,curve,group", GROUPS)
 def test_batch_exp_matches_reference(port, ref, name, curve, group):
     bits = ref.sizes(curve, group)["fr_bits"]
     g = ref.group_op(curve, group, 2, ref.bases_seq(curve, group, 1, first=6)[0])
