@@ -155,6 +155,10 @@ def main():
     ap.add_argument("--also-pipelined", type=int, default=2,
                     help="after the timed region, also measure the same workload with this many MSMs in flight "
                          "(reported under 'pipelined'); 0 disables")
+    ap.add_argument("--precomputed-c", type=int, default=16,
+                    help="also time the precomputed-multiples MSM (multi_exp_stream_with_precompute's algorithm on an "
+                         "HBM-resident table of [2^(jc)]P) with this window size (reported under 'precomputed'); "
+                         "0 disables")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -256,6 +260,45 @@ def main():
                              "comparable with the un-overlapped ones, so `value` stays the depth-1 figure"}
         msm = ShardedMsm(eng, curve, group, depth=1)
 
+    # ---- fixed bases with precomputed multiples (multi_exp_stream_with_precompute, HBM-resident) ----
+    precomputed = None
+    if args.precomputed_c:
+        pc = args.precomputed_c
+        D = libff_amd.precompute_num_digits(curve, pc)
+        table = torch.empty((n * D, sz["affine_bytes"] // 8), dtype=torch.int64, device=dev)
+        tb = time.perf_counter()
+        eng.precompute_bases_device(curve, group, bases.data_ptr(), n, pc, D, table.data_ptr(), stream=stream)
+        torch.cuda.synchronize()
+        build_s = time.perf_counter() - tb
+        out_pt = torch.zeros(sz["g_bytes"] // 8, dtype=torch.int64, device=dev)
+        for _ in range(2):
+            eng.msm_precomputed_device(curve, group, table.data_ptr(), scalars.data_ptr(), n, pc, D, out_pt.data_ptr(),
+                                       stream=stream)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        kq = max(args.steps, 4)
+        tq = time.perf_counter()
+        for _ in range(kq):
+            eng.msm_precomputed_device(curve, group, table.data_ptr(), scalars.data_ptr(), n, pc, D, out_pt.data_ptr(),
+                                       stream=stream)
+        phq = eng.get_timings()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        eq = time.perf_counter() - tq
+        if world > 1:
+            tt = torch.tensor([eq], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            eq = float(tt.item())
+        precomputed = {"window_bits": pc, "multiples_per_base": D, "table_gib": table.numel() * 8 / 2**30,
+                       "table_build_ms": build_s * 1e3, "steps": kq, "value": n * world * kq / eq,
+                       "unit": "scalar-muls/s", "ms_per_step": eq / kq * 1e3, "phases_ms_last": phq,
+                       "note": "libff's multi_exp_stream_with_precompute algorithm (one bucket set over the table "
+                               "[2^(jc)]P_i, no doublings) with the table resident in HBM; per-rank results are not "
+                               "combined in this leg; a different reference entry point than `value`'s multi_exp"}
+        del table
+
     # ---- second size of the metric (2^26 by default), outside the main timed region ----
     also = None
     if args.extra_log2n and args.extra_log2n != args.log2n:
@@ -338,6 +381,8 @@ def main():
         }
         if pipelined is not None:
             out["pipelined"] = pipelined
+        if precomputed is not None:
+            out["precomputed"] = precomputed
         if also is not None:
             out["also"] = also
         if world == 1 and not args.no_cpu_baseline:

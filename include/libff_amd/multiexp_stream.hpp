@@ -4,7 +4,9 @@
 // specialisation forwards the istream to the engine through a reader callback
 // (amdmsm_multi_exp_stream), so the bases are decoded and consumed on the device chunk by chunk
 // instead of by the reference's reader thread + SPSC fifo (multiexp_stream.tcc:164-191).
-// Other Form / Comp combinations keep the reference body.
+// libff::multi_exp_stream_with_precompute<form_montgomery, compression_off, GroupT, FieldT>(
+// std::istream &, exponents, precompute_c) (multiexp_stream.hpp:29-42) is routed the same way to
+// amdmsm_multi_exp_stream_with_precompute.  Other Form / Comp combinations keep the reference body.
 #ifndef LIBFF_AMD_MULTIEXP_STREAM_HPP_
 #define LIBFF_AMD_MULTIEXP_STREAM_HPP_
 
@@ -50,6 +52,36 @@ GroupT gpu_multi_exp_stream(
     return result;
 }
 
+template<typename GroupT, typename FieldT>
+GroupT gpu_multi_exp_stream_with_precompute(
+    std::istream &precomputed_elements_in,
+    const std::vector<FieldT> &exponents,
+    const size_t precompute_c)
+{
+    GroupT result = GroupT::zero();
+    amdmsm_opts opts = {};
+    opts.out_form = AMDMSM_OUT_LIBFF;
+    const int rc = amdmsm_multi_exp_stream_with_precompute(
+        default_context(),
+        group_id<GroupT>::curve,
+        group_id<GroupT>::group,
+        istream_reader,
+        static_cast<void *>(&precomputed_elements_in),
+        exponents.empty() ? nullptr : static_cast<const void *>(exponents.data()),
+        exponents.size(),
+        precompute_c,
+        0,
+        static_cast<void *>(&result.X),
+        &opts);
+    if (rc != AMDMSM_OK) {
+        throw std::runtime_error(
+            std::string("libff_amd: amdmsm_multi_exp_stream_with_precompute failed: ") +
+            amdmsm_strerror(rc) + " (" +
+            amdmsm_last_error(default_context()) + ")");
+    }
+    return result;
+}
+
 } // namespace libff_amd
 
 #define LIBFF_AMD_ROUTE_STREAM(GROUP_T, FIELD_T)                               \
@@ -63,6 +95,20 @@ GroupT gpu_multi_exp_stream(
     {                                                                          \
         return libff_amd::gpu_multi_exp_stream<GROUP_T, FIELD_T>(              \
             base_elements_in, exponents);                                      \
+    }                                                                          \
+    template<>                                                                 \
+    inline GROUP_T multi_exp_stream_with_precompute<                           \
+        form_montgomery,                                                       \
+        compression_off,                                                       \
+        GROUP_T,                                                               \
+        FIELD_T>(                                                              \
+        std::istream & precomputed_elements_in,                                \
+        const std::vector<FIELD_T> &exponents,                                 \
+        const size_t precompute_c)                                             \
+    {                                                                          \
+        return libff_amd::gpu_multi_exp_stream_with_precompute<               \
+            GROUP_T,                                                           \
+            FIELD_T>(precomputed_elements_in, exponents, precompute_c);        \
     }                                                                          \
     }
 

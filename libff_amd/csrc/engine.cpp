@@ -136,6 +136,7 @@ int make_plan(const group_vtable *vt, size_t n, int c_req, int L_req, plan_t &p,
     // lanes to fill the chip; short ones keep the latency down for small bucket counts
     uint32_t L = 8u;
     while (L < 32u && (size_t)p.W * p.B / (2 * L) >= (size_t)262144) L <<= 1;
+    while (L > 2u && (size_t)p.W * p.B / L < (size_t)16384) L >>= 1;
     if (L_req > 0) L = (uint32_t)L_req;
     while (L > p.B) L >>= 1;
     if (L == 0 || (L & (L - 1))) return AMDMSM_ERR_BAD_ARG;
@@ -172,7 +173,7 @@ int make_plan(const group_vtable *vt, size_t n, int c_req, int L_req, plan_t &p,
     p.off_cont = off;
     off = align_up(off + (size_t)p.W * p.T * 4, 256);
     p.off_queue = off;
-    off = align_up(off + (2 + 2 * ((size_t)p.W * p.T / 24 + 2)) * 4, 256);
+    off = align_up(off + fixup_queue_words((size_t)p.W * p.T) * 4, 256);
     // two-level sort scratch
     p.off_coarse = off;
     off = align_up(off + (size_t)p.W * 1025 * 4, 256);

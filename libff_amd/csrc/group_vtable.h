@@ -36,6 +36,17 @@ inline sort_geom sort_geometry(size_t n, int c, int W) {
     return g;
 }
 
+// Queues of buckets whose entries span several accumulation lanes (k_accumulate_fixup):
+// spans of more than 32 lanes ("long") and of 3..32 lanes ("mid"), `lanes` = W * T.
+#ifdef __HIPCC__
+#define AMDMSM_HD __host__ __device__
+#else
+#define AMDMSM_HD
+#endif
+AMDMSM_HD inline size_t fixup_queue_cap_long(size_t lanes) { return lanes / 32 + 2; }
+AMDMSM_HD inline size_t fixup_queue_cap_mid(size_t lanes) { return lanes / 3 + 2; }
+inline size_t fixup_queue_words(size_t lanes) { return 2 + 2 * (fixup_queue_cap_long(lanes) + fixup_queue_cap_mid(lanes)); }
+
 struct group_vtable {
     int curve, group;
     int fr_words;      // 32-bit words per scalar
@@ -68,7 +79,7 @@ struct group_vtable {
     // ends are those of a single window and big is sized by sort_geometry(n*W, c, 1)
     // segmented bucket sums: lane t of window w owns list entries [t*S, (t+1)*S); buckets[]
     // must be zero-filled; part_first / part_last: W*T points, cont_bucket: W*T words;
-    // long_queue: 2 + 2*(W*T/24 + 1) words, word 0 zeroed (queue of buckets spanning many lanes)
+    // long_queue: fixup_queue_words(W*T) words, the first two zeroed (buckets spanning many lanes)
     void (*accumulate)(hipStream_t, const uint32_t* ends, const uint32_t* lists, size_t list_stride,
                        const uint32_t* bases_affine, uint32_t* buckets, uint32_t* part_first, uint32_t* part_last,
                        uint32_t* cont_bucket, uint32_t* long_queue, int W, uint32_t B, uint32_t S, uint32_t T,

@@ -753,30 +753,54 @@ __global__ void __launch_bounds__(TPB) k_accumulate(const uint32_t* __restrict__
 
 AMDMSM_DEV void wave_group_sum(Jac<E>& p, uint32_t G);
 
-// Spans of up to LONG_SPAN lanes are closed by the lane's own thread; longer ones (a bucket
-// holding a large share of a window) are queued and closed by a whole wave each.
-constexpr uint32_t LONG_SPAN = 24;
+// Closing the spanning buckets.  A span of up to INLINE_SPAN further lanes is summed by the
+// lane's own thread (the common case: buckets of about S entries); longer ones are queued and
+// closed by MID_G lanes each (up to MID_SPAN lanes: buckets of a few thousand entries, the
+// regime of a precomputed-table MSM or a short top window) or by a whole wave (a bucket holding
+// a large share of the input), so that no wave idles behind a single long serial sum.
+constexpr uint32_t INLINE_SPAN = 2;
+constexpr uint32_t MID_SPAN = 32;
+constexpr uint32_t MID_G = 8;
+
+// queue layout (fixup_queue_words): [0] long count, [1] mid count, long entries, mid entries
+AMDMSM_DEV uint32_t* fixup_queue_base(uint32_t* q, size_t lanes, int mid) {
+    return q + 2 + (mid ? 2 * fixup_queue_cap_long(lanes) : 0);
+}
 
 __global__ void __launch_bounds__(64) k_accumulate_fixup(const uint32_t* __restrict__ ends,
                                                          const uint32_t* __restrict__ part_first,
                                                          const uint32_t* __restrict__ part_last,
                                                          const uint32_t* __restrict__ cont_bucket,
-                                                         uint32_t* __restrict__ buckets, uint32_t* __restrict__ long_queue,
+                                                         uint32_t* __restrict__ buckets, uint32_t* __restrict__ queue,
                                                          int W, uint32_t B, uint32_t S, uint32_t T) {
     const size_t g = gtid();
     const size_t w = g / T;
     const uint32_t t = (uint32_t)(g % T);
-    if (w >= (size_t)W) return;
-    const uint32_t b = cont_bucket[g];
-    if (b == NO_BUCKET) return;
-    const uint32_t bend = ends[w * B + b];
-    const uint32_t t_last = (bend - 1) / S;   // lane holding the bucket's last entry
-    if (t_last - t > LONG_SPAN) {
-        const uint32_t slot = atomicAdd(&long_queue[0], 1u);
-        long_queue[2 + 2 * (size_t)slot] = (uint32_t)g;
-        long_queue[3 + 2 * (size_t)slot] = (uint32_t)(g >> 32);
-        return;
+    uint32_t b = NO_BUCKET, t_last = 0;
+    if (w < (size_t)W) {
+        b = cont_bucket[g];
+        if (b != NO_BUCKET) t_last = (ends[w * B + b] - 1) / S;   // lane holding the bucket's last entry
     }
+    const uint32_t span = (b != NO_BUCKET) ? t_last - t : 0;
+    // queue the longer spans, one atomic per wave and class
+    const size_t lanes = (size_t)W * T;
+#pragma unroll
+    for (int mid = 0; mid < 2; ++mid) {
+        const bool mine = mid ? (span > INLINE_SPAN && span <= MID_SPAN) : (span > MID_SPAN);
+        const unsigned long long m = __ballot(mine);
+        if (m == 0) continue;
+        const uint32_t lane = threadIdx.x & 63u;
+        uint32_t base = 0;
+        if (lane == (uint32_t)__ffsll((long long)m) - 1u) base = atomicAdd(&queue[mid], (uint32_t)__popcll(m));
+        base = (uint32_t)__shfl((int)base, __ffsll((long long)m) - 1, 64);
+        if (mine) {
+            const uint32_t slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            uint32_t* q = fixup_queue_base(queue, lanes, mid);
+            q[2 * (size_t)slot] = (uint32_t)g;
+            q[2 * (size_t)slot + 1] = (uint32_t)(g >> 32);
+        }
+    }
+    if (span == 0 || span > INLINE_SPAN) return;
     Xyzz<E> acc, x;
     load_xyzz(acc, part_last + g * ZZW);
     for (uint32_t u = t + 1; u <= t_last; ++u) {
@@ -821,41 +845,56 @@ __global__ void __launch_bounds__(64) k_accumulate_compact(const uint32_t* __res
     if (lane == 0) store_xyzz(part_first + (w * T + first) * ZZW, acc);
 }
 
-// one wave per queued bucket: lanes stride over its partials (one per folded block, see
-// k_accumulate_compact), XOR butterfly, lane 0 stores
-__global__ void __launch_bounds__(64) k_accumulate_fixup_long(const uint32_t* __restrict__ ends,
-                                                              const uint32_t* __restrict__ part_first,
-                                                              const uint32_t* __restrict__ part_last,
-                                                              const uint32_t* __restrict__ cont_bucket,
-                                                              uint32_t* __restrict__ buckets,
-                                                              const uint32_t* __restrict__ long_queue, uint32_t B,
-                                                              uint32_t S, uint32_t T) {
-    const uint32_t count = long_queue[0];
-    const uint32_t lane = threadIdx.x & 63u;
-    for (uint32_t q = blockIdx.x; q < count; q += gridDim.x) {
-        const size_t g = (size_t)long_queue[2 + 2 * (size_t)q] | ((size_t)long_queue[3 + 2 * (size_t)q] << 32);
-        const size_t w = g / T;
-        const uint32_t t = (uint32_t)(g % T);
-        const uint32_t b = cont_bucket[g];
-        const uint32_t t_last = (ends[w * B + b] - 1) / S;
+// G lanes per queued bucket (G = 64 for the long queue, MID_G for the mid queue): the lanes
+// stride over its partials (one per folded block, see k_accumulate_compact), XOR butterfly,
+// the group's first lane stores
+__global__ void __launch_bounds__(64) k_accumulate_fixup_queue(const uint32_t* __restrict__ ends,
+                                                               const uint32_t* __restrict__ part_first,
+                                                               const uint32_t* __restrict__ part_last,
+                                                               const uint32_t* __restrict__ cont_bucket,
+                                                               uint32_t* __restrict__ buckets,
+                                                               const uint32_t* __restrict__ queue, int mid, uint32_t G,
+                                                               size_t lanes, uint32_t B, uint32_t S, uint32_t T) {
+    const uint32_t count = queue[mid];
+    const uint32_t* qb = queue + 2 + (mid ? 2 * fixup_queue_cap_long(lanes) : 0);
+    // every field product costs a wave about a microsecond whatever its lane count, so with
+    // many queued buckets fewer lanes each (about one wave per SIMD in total) finish sooner
+    if (mid) {
+        while (G > 1 && (size_t)count * G > 65536) G >>= 1;
+    }
+    const uint32_t per_wave = 64u / G;
+    const uint32_t sub = (threadIdx.x & 63u) / G, lane = (threadIdx.x & 63u) % G;
+    for (uint32_t q0 = blockIdx.x * per_wave; q0 < count; q0 += gridDim.x * per_wave) {
+        const uint32_t q = q0 + sub;
+        const bool live = q < count;
         Xyzz<E> acc, x;
-        if (lane == 0) load_xyzz(acc, part_last + g * ZZW); else xyzz_set_inf(acc);
-        // lanes t+1 .. t_last = head [t+1, h), nb folded blocks from h, tail [tail0, t_last]
-        uint32_t h = (t + 1 + FIX_BLOCK - 1) / FIX_BLOCK * FIX_BLOCK;
-        uint32_t nb = 0;
-        if (h <= t_last + 1) nb = (t_last + 1 - h) / FIX_BLOCK; else h = t_last + 1;
-        const uint32_t nh = h - (t + 1), tail0 = h + nb * FIX_BLOCK;
-        const uint32_t items = nh + nb + (t_last + 1 - tail0);
-        for (uint32_t i = lane; i < items; i += 64) {
-            const uint32_t u = i < nh ? t + 1 + i : (i < nh + nb ? h + (i - nh) * FIX_BLOCK : tail0 + (i - nh - nb));
-            load_xyzz(x, part_first + (w * T + u) * ZZW);
-            xyzz_add(acc, acc, x);
+        xyzz_set_inf(acc);
+        size_t w = 0;
+        uint32_t b = 0;
+        if (live) {
+            const size_t g = (size_t)qb[2 * (size_t)q] | ((size_t)qb[2 * (size_t)q + 1] << 32);
+            w = g / T;
+            const uint32_t t = (uint32_t)(g % T);
+            b = cont_bucket[g];
+            const uint32_t t_last = (ends[w * B + b] - 1) / S;
+            if (lane == 0) load_xyzz(acc, part_last + g * ZZW);
+            // lanes t+1 .. t_last = head [t+1, h), nb folded blocks from h, tail [tail0, t_last]
+            uint32_t h = (t + 1 + FIX_BLOCK - 1) / FIX_BLOCK * FIX_BLOCK;
+            uint32_t nb = 0;
+            if (h <= t_last + 1) nb = (t_last + 1 - h) / FIX_BLOCK; else h = t_last + 1;
+            const uint32_t nh = h - (t + 1), tail0 = h + nb * FIX_BLOCK;
+            const uint32_t items = nh + nb + (t_last + 1 - tail0);
+            for (uint32_t i = lane; i < items; i += G) {
+                const uint32_t u = i < nh ? t + 1 + i : (i < nh + nb ? h + (i - nh) * FIX_BLOCK : tail0 + (i - nh - nb));
+                load_xyzz(x, part_first + (w * T + u) * ZZW);
+                xyzz_add(acc, acc, x);
+            }
         }
         Jac<E> j;
         xyzz_to_jac(j, acc);
-        wave_group_sum(j, 64);
+        wave_group_sum(j, G);
         jac_to_xyzz(acc, j);
-        if (lane == 0) store_xyzz(buckets + (w * B + b) * ZZW, acc);
+        if (live && lane == 0) store_xyzz(buckets + (w * B + b) * ZZW, acc);
     }
 }
 
@@ -1502,9 +1541,12 @@ void l_accumulate(hipStream_t st, const uint32_t* ends, const uint32_t* lists, s
                            part_first, W, B, S, T);
     hipLaunchKernelGGL(k_accumulate_fixup, dim3(blocks_for((size_t)W * T, 64)), dim3(64), 0, st, ends, part_first,
                        part_last, cont_bucket, buckets, long_queue, W, B, S, T);
-    const size_t max_long = (size_t)W * T / LONG_SPAN + 1;
-    hipLaunchKernelGGL(k_accumulate_fixup_long, dim3((unsigned)(max_long < 2048 ? max_long : 2048)), dim3(64), 0, st, ends,
-                       part_first, part_last, cont_bucket, buckets, long_queue, B, S, T);
+    const size_t lanes = (size_t)W * T;
+    const size_t cap_mid = fixup_queue_cap_mid(lanes) / (64 / MID_G) + 1, cap_long = fixup_queue_cap_long(lanes);
+    hipLaunchKernelGGL(k_accumulate_fixup_queue, dim3((unsigned)(cap_mid < 8192 ? cap_mid : 8192)), dim3(64), 0, st, ends,
+                       part_first, part_last, cont_bucket, buckets, long_queue, 1, MID_G, lanes, B, S, T);
+    hipLaunchKernelGGL(k_accumulate_fixup_queue, dim3((unsigned)(cap_long < 2048 ? cap_long : 2048)), dim3(64), 0, st, ends,
+                       part_first, part_last, cont_bucket, buckets, long_queue, 0, 64u, lanes, B, S, T);
 }
 void l_reduce_segments(hipStream_t st, const uint32_t* buckets, int W, uint32_t B, uint32_t L, uint32_t* out) {
     hipLaunchKernelGGL(k_reduce_segments, dim3(blocks_for((size_t)W * (B / L), 64)), dim3(64), 0, st, buckets, W, B, L, out);

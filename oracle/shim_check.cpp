@@ -81,6 +81,25 @@ template<typename G, typename Fr> void check_group(const char *name, const std::
             const G rs = multi_exp_stream<form_montgomery, compression_off, G, Fr>(ss, scalars);
             ok = ok && (expect == rs);
         }
+        // precomputed multiples, laid out as create_precompute_file_for_config does
+        // (profile_multiexp.cpp:120-150); c = 7 leaves spare bits in the top digit of every Fr
+        // here, so the routed multi_exp_stream_with_precompute must return the plain sum
+        if (n <= 600) {
+            const size_t c = 7;
+            const size_t entries = (Fr::num_bits + c - 1) / c;
+            std::stringstream ss(std::ios_base::in | std::ios_base::out | std::ios_base::binary);
+            for (G el : special) {
+                group_write<encoding_binary, form_montgomery, compression_off>(el, ss);
+                for (size_t i = 0; i + 1 < entries; ++i) {
+                    for (size_t j = 0; j < c; ++j) {
+                        el = el.dbl();
+                    }
+                    group_write<encoding_binary, form_montgomery, compression_off>(el, ss);
+                }
+            }
+            const G rp = multi_exp_stream_with_precompute<form_montgomery, compression_off, G, Fr>(ss, scalars, c);
+            ok = ok && (expect == rp);
+        }
         printf("%-14s n=%-6zu %s\n", name, n, ok ? "ok" : "MISMATCH");
         if (!ok) {
             ++failures;
