@@ -22,11 +22,20 @@ using namespace amdmsm;
 // may overlap on the device (the small-grid tail of one MSM under the bulk kernels of the
 // next); a slot is reused only after the call that last used it has finished (event wait).
 constexpr int MAX_SLOTS = 4;
+// Window groups of one MSM (experimental, off by default: AMDMSM_WINDOW_GROUPS=2..4): the windows
+// are accumulated group by group on the caller's stream, highest first; the tail of a finished
+// group (bucket fix-up, reduction, its share of the Horner chain) runs on a side stream under
+// the accumulation of the next group.  Measured gain is only ~3% at 2^20..2^22 and ~1% at 2^26:
+// the tail kernels are short on parallelism, not on issue slots, and slow down 2-3x when they
+// share SIMDs with k_accumulate.
+constexpr int MAX_GROUPS = 4;
 struct ws_slot {
     void *ws = nullptr;
     size_t ws_bytes = 0;
     hipEvent_t done = nullptr;
     bool used = false;
+    hipStream_t side[MAX_GROUPS - 1] = {};
+    hipEvent_t acc_done[MAX_GROUPS - 1] = {}, tail_done[MAX_GROUPS - 1] = {};
     hipEvent_t ev[AMDMSM_MAX_PHASES + 1] = {};
     bool ev_valid = false;
 };
@@ -88,6 +97,8 @@ size_t libff_log2(size_t n) {
 struct plan_t {
     int c = 0, W = 0;
     int D = 0;   // > 0: precomputed-table mode, D digits per scalar in one bucket set (W == 1)
+    int G = 1;   // window groups (see ws_slot)
+    size_t queue_stride = 0, off_partial = 0;
     uint32_t B = 0, L = 0;
     uint32_t S = 0, T = 0;   // entries per accumulation lane, lanes per window
     size_t off_counts = 0, off_lists = 0, off_buckets = 0, off_lvl0 = 0, off_lvl1 = 0, total = 0;
@@ -123,7 +134,8 @@ int choose_c(const group_vtable *vt, size_t n) {
 
 // table_digits > 0: every scalar contributes table_digits entries (one per digit, pointing at
 // its precomputed multiple) to a single bucket set; n is then the number of ENTRIES.
-int make_plan(const group_vtable *vt, size_t n, int c_req, int L_req, plan_t &p, int S_req = 0, int table_digits = 0) {
+int make_plan(const group_vtable *vt, size_t n, int c_req, int L_req, plan_t &p, int S_req = 0, int table_digits = 0,
+              int G_req = 0) {
     if (c_req < 0 || c_req > 24 || c_req == 1) return AMDMSM_ERR_BAD_ARG;
     if (table_digits && (c_req < 2 || c_req > 22)) return AMDMSM_ERR_BAD_ARG;
     p.c = c_req ? c_req : choose_c(vt, n);
@@ -172,8 +184,12 @@ int make_plan(const group_vtable *vt, size_t n, int c_req, int L_req, plan_t &p,
     off = align_up(off + (size_t)p.W * p.T * zz_bytes, 256);
     p.off_cont = off;
     off = align_up(off + (size_t)p.W * p.T * 4, 256);
-    p.off_queue = off;
-    off = align_up(off + fixup_queue_words((size_t)p.W * p.T) * 4, 256);
+    p.G = G_req > 0 ? std::min(std::min(G_req, MAX_GROUPS), p.W) : 1;
+    p.off_queue = off;   // one fix-up queue per group, each sized for the largest group
+    p.queue_stride = align_up(fixup_queue_words((size_t)((p.W + p.G - 1) / p.G) * p.T) * 4, 256);
+    off = off + p.queue_stride * p.G;
+    p.off_partial = off;
+    off = align_up(off + (size_t)MAX_GROUPS * xyz_bytes, 256);
     // two-level sort scratch
     p.off_coarse = off;
     off = align_up(off + (size_t)p.W * 1025 * 4, 256);
@@ -238,7 +254,9 @@ int msm_device_impl(amdmsm_ctx *ctx, const group_vtable *vt, const uint32_t *d_b
     plan_t p;
     // tuning knobs for experiments: AMDMSM_ACC_S (entries per accumulation lane)
     static const int acc_s_env = getenv("AMDMSM_ACC_S") ? atoi(getenv("AMDMSM_ACC_S")) : 0;
-    int rc = make_plan(vt, entries, opts ? opts->window_bits : 0, opts ? opts->segment_len : 0, p, acc_s_env, table_digits);
+    static const int groups_env = getenv("AMDMSM_WINDOW_GROUPS") ? atoi(getenv("AMDMSM_WINDOW_GROUPS")) : 0;
+    int rc = make_plan(vt, entries, opts ? opts->window_bits : 0, opts ? opts->segment_len : 0, p, acc_s_env, table_digits,
+                       groups_env);
     if (rc) return fail(ctx, rc, "bad window_bits / segment_len");
     const int slot_idx = (int)(ctx->next++ % (unsigned)ctx->depth);
     ws_slot &sl = ctx->slots[slot_idx];
@@ -270,21 +288,50 @@ int msm_device_impl(amdmsm_ctx *ctx, const group_vtable *vt, const uint32_t *d_b
                  table_digits ? 1 : 0);
     }
     HIP_TRY(ctx, hipMemsetAsync(buckets, 0, (size_t)p.W * p.B * vt->el_words * 16, st));
-    HIP_TRY(ctx, hipMemsetAsync(ws + p.off_queue, 0, 8, st));
-    vt->accumulate(st, counts, lists, p.list_stride, d_bases, buckets, (uint32_t *)(ws + p.off_pfirst),
-                   (uint32_t *)(ws + p.off_plast), (uint32_t *)(ws + p.off_cont), (uint32_t *)(ws + p.off_queue), p.W,
-                   p.B, p.S, p.T, ctx->timing ? sl.ev[2] : nullptr, ctx->timing ? sl.ev[3] : nullptr);
-    vt->reduce_segments(st, buckets, p.W, p.B, p.L, lvl0);
-    uint32_t M = p.B / p.L;
-    M /= std::min<uint32_t>(M, 64u);   // folded per wave inside reduce_segments
-    uint32_t *src = lvl0, *dst = lvl1;
-    while (M > 1) {
-        vt->sum_butterfly(st, src, p.W, M, dst);
-        M /= std::min<uint32_t>(M, 64u);
-        std::swap(src, dst);
+    for (int g = 0; g < p.G; ++g) HIP_TRY(ctx, hipMemsetAsync(ws + p.off_queue + g * p.queue_stride, 0, 8, st));
+    const size_t zzw = (size_t)vt->el_words * 4, xyzw = (size_t)vt->el_words * 3;   // words per XYZZ / Jacobian point
+    const size_t M0 = p.B / p.L, cap1 = (M0 + p.L - 1) / p.L;
+    uint32_t *pfirst = (uint32_t *)(ws + p.off_pfirst), *plast = (uint32_t *)(ws + p.off_plast);
+    uint32_t *cont = (uint32_t *)(ws + p.off_cont), *partial = (uint32_t *)(ws + p.off_partial);
+    // groups of windows, highest first: [w0, w0 + wg)
+    int w_hi = p.W;
+    for (int g = 0; g < p.G; ++g) {
+        const int wg = p.W / p.G + (g < p.W % p.G ? 1 : 0);
+        const int w0 = w_hi - wg;
+        w_hi = w0;
+        const bool last = g == p.G - 1;
+        // accumulation group after group on the caller's stream; the tail of a finished group
+        // moves to a side stream
+        hipStream_t ts = last ? st : sl.side[g];
+        if (g == 0) record(ctx, sl, 2, st);
+        vt->accumulate(st, counts + (size_t)w0 * p.B, lists + (size_t)w0 * p.list_stride, p.list_stride, d_bases,
+                       buckets + (size_t)w0 * p.B * zzw, pfirst + (size_t)w0 * p.T * zzw, plast + (size_t)w0 * p.T * zzw,
+                       cont + (size_t)w0 * p.T, wg, p.B, p.S, p.T);
+        if (last) {
+            record(ctx, sl, 3, st);
+        } else {
+            HIP_TRY(ctx, hipEventRecord(sl.acc_done[g], st));
+            HIP_TRY(ctx, hipStreamWaitEvent(ts, sl.acc_done[g], 0));
+        }
+        vt->accumulate_fixup(ts, counts + (size_t)w0 * p.B, buckets + (size_t)w0 * p.B * zzw,
+                             pfirst + (size_t)w0 * p.T * zzw, plast + (size_t)w0 * p.T * zzw, cont + (size_t)w0 * p.T,
+                             (uint32_t *)(ws + p.off_queue + g * p.queue_stride), wg, p.B, p.S, p.T);
+        uint32_t *src = lvl0 + (size_t)w0 * M0 * xyzw, *dst = lvl1 + (size_t)w0 * cap1 * xyzw;
+        vt->reduce_segments(ts, buckets + (size_t)w0 * p.B * zzw, wg, p.B, p.L, src);
+        uint32_t M = (uint32_t)M0;
+        M /= std::min<uint32_t>(M, 64u);   // folded per wave inside reduce_segments
+        while (M > 1) {
+            vt->sum_butterfly(ts, src, wg, M, dst);
+            M /= std::min<uint32_t>(M, 64u);
+            std::swap(src, dst);
+        }
+        // Horner over this group's windows, continuing from the groups above
+        if (g > 0) HIP_TRY(ctx, hipStreamWaitEvent(ts, sl.tail_done[g - 1], 0));
+        if (last) record(ctx, sl, 4, st);
+        vt->horner(ts, src, wg, p.c, last ? form : (int)AMDMSM_OUT_JACOBIAN, g > 0 ? partial + (size_t)(g - 1) * xyzw : nullptr,
+                   last ? d_out : partial + (size_t)g * xyzw);
+        if (!last) HIP_TRY(ctx, hipEventRecord(sl.tail_done[g], ts));
     }
-    record(ctx, sl, 4, st);
-    vt->horner(st, src, p.W, p.c, form, d_out);
     record(ctx, sl, 5, st);
     sl.ev_valid = ctx->timing;
     HIP_TRY(ctx, hipEventRecord(sl.done, st));
@@ -342,6 +389,9 @@ int amdmsm_ctx_create(int device, amdmsm_ctx **out) {
     for (auto &sl : ctx->slots) {
         bool ok = hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) == hipSuccess;
         for (auto &e : sl.ev) ok = ok && hipEventCreate(&e) == hipSuccess;
+        for (auto &e : sl.tail_done) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+        for (auto &e : sl.acc_done) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+        for (auto &q : sl.side) ok = ok && hipStreamCreateWithFlags(&q, hipStreamNonBlocking) == hipSuccess;
         if (!ok) {
             delete ctx;
             return AMDMSM_ERR_HIP;
@@ -361,6 +411,15 @@ void amdmsm_ctx_destroy(amdmsm_ctx *ctx) {
             if (sl.done) (void)hipEventDestroy(sl.done);
             for (auto &e : sl.ev) {
                 if (e) (void)hipEventDestroy(e);
+            }
+            for (auto &e : sl.acc_done) {
+                if (e) (void)hipEventDestroy(e);
+            }
+            for (auto &e : sl.tail_done) {
+                if (e) (void)hipEventDestroy(e);
+            }
+            for (auto &q : sl.side) {
+                if (q) (void)hipStreamDestroy(q);
             }
         }
         for (auto &e : ctx->ev) {

@@ -78,19 +78,26 @@ struct group_vtable {
     // bucket set (their payload indexes a precompute_table); then stride >= n*W, coarse / cursor /
     // ends are those of a single window and big is sized by sort_geometry(n*W, c, 1)
     // segmented bucket sums: lane t of window w owns list entries [t*S, (t+1)*S); buckets[]
-    // must be zero-filled; part_first / part_last: W*T points, cont_bucket: W*T words;
-    // long_queue: fixup_queue_words(W*T) words, the first two zeroed (buckets spanning many lanes)
+    // must be zero-filled; part_first / part_last: W*T points, cont_bucket: W*T words.
+    // Every array argument is the start of window 0 of the call, so a sub-range of windows is
+    // processed by passing offset pointers and its window count.
     void (*accumulate)(hipStream_t, const uint32_t* ends, const uint32_t* lists, size_t list_stride,
                        const uint32_t* bases_affine, uint32_t* buckets, uint32_t* part_first, uint32_t* part_last,
-                       uint32_t* cont_bucket, uint32_t* long_queue, int W, uint32_t B, uint32_t S, uint32_t T,
-                       hipEvent_t before_main, hipEvent_t after_main);   // events bracket k_accumulate alone (may be null)
+                       uint32_t* cont_bucket, int W, uint32_t B, uint32_t S, uint32_t T);
+    // closes the buckets that span several lanes; queue: fixup_queue_words(W*T) words, the
+    // first two zeroed
+    void (*accumulate_fixup)(hipStream_t, const uint32_t* ends, uint32_t* buckets, uint32_t* part_first,
+                             const uint32_t* part_last, const uint32_t* cont_bucket, uint32_t* queue, int W,
+                             uint32_t B, uint32_t S, uint32_t T);
     // M = B/L segments per window, G = min(M, 64):
     // out[w][g] = sum over segments s in [g*G, (g+1)*G) of sum_j (s*L + j + 1) * bucket[w][s*L + j]
     void (*reduce_segments)(hipStream_t, const uint32_t* buckets, int W, uint32_t B, uint32_t L, uint32_t* out);
     // out[w][g] = sum_{i in [g*G, (g+1)*G)} in[w][i], G = min(M, 64)
     void (*sum_butterfly)(hipStream_t, const uint32_t* in, int W, uint32_t M, uint32_t* out);
-    // Horner over window sums (high to low, c doublings between), write one point
-    void (*horner)(hipStream_t, const uint32_t* window_sums, int W, int c, int form, uint32_t* out);
+    // Horner over window sums (high to low, c doublings between), write one point; init (engine
+    // Jacobian, may be null) = value carried in from the windows above window_sums[W-1]
+    void (*horner)(hipStream_t, const uint32_t* window_sums, int W, int c, int form, const uint32_t* init,
+                   uint32_t* out);
     // sum of k engine-Jacobian points
     void (*sum_points)(hipStream_t, const uint32_t* pts, int k, int form, uint32_t* out);
     // synthetic bases: dst[i] = (first + i + 1) * G::one(), compact affine

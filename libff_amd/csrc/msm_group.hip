@@ -963,10 +963,18 @@ __global__ void __launch_bounds__(64) k_sum_butterfly(const uint32_t* __restrict
 // (multiexp.tcc:612-629).  One wave; every lane carries the same running point so the
 // doublings can borrow lanes 0..2 for their field products (jac_dbl_lanes3).
 __global__ void __launch_bounds__(64) k_horner(const uint32_t* __restrict__ window_sums, int W, int c, int form,
-                                               uint32_t* __restrict__ out) {
+                                               const uint32_t* __restrict__ init, uint32_t* __restrict__ out) {
+    // init: running value handed over by the windows above this group (they are combined on
+    // another stream while the windows of this group are still being accumulated)
     Jac<E> res, x;
-    load_jac(res, window_sums + (size_t)(W - 1) * XYZW);
-    for (int w = W - 2; w >= 0; --w) {
+    int w = W - 1;
+    if (init) {
+        load_jac(res, init);
+    } else {
+        load_jac(res, window_sums + (size_t)w * XYZW);
+        --w;
+    }
+    for (; w >= 0; --w) {
         for (int i = 0; i < c; ++i) jac_dbl_lanes3(res);
         load_jac(x, window_sums + (size_t)w * XYZW);
         jac_add(res, res, x);
@@ -1529,24 +1537,25 @@ void l_sort(hipStream_t st, const uint32_t* scalars, size_t n, int mont, int c, 
                        hb, sg.big_cap, big, lists);
 }
 void l_accumulate(hipStream_t st, const uint32_t* ends, const uint32_t* lists, size_t list_stride, const uint32_t* bases,
-                  uint32_t* buckets, uint32_t* part_first, uint32_t* part_last, uint32_t* cont_bucket,
-                  uint32_t* long_queue, int W, uint32_t B, uint32_t S, uint32_t T, hipEvent_t before_main,
-                  hipEvent_t after_main) {
-    if (before_main) (void)hipEventRecord(before_main, st);
+                  uint32_t* buckets, uint32_t* part_first, uint32_t* part_last, uint32_t* cont_bucket, int W, uint32_t B,
+                  uint32_t S, uint32_t T) {
     hipLaunchKernelGGL(k_accumulate, dim3(blocks_for((size_t)W * T)), dim3(TPB), 0, st, ends, lists, list_stride, bases,
                        buckets, part_first, part_last, cont_bucket, W, B, S, T);
-    if (after_main) (void)hipEventRecord(after_main, st);
+}
+void l_accumulate_fixup(hipStream_t st, const uint32_t* ends, uint32_t* buckets, uint32_t* part_first,
+                        const uint32_t* part_last, const uint32_t* cont_bucket, uint32_t* queue, int W, uint32_t B,
+                        uint32_t S, uint32_t T) {
     if (T / FIX_BLOCK >= 2)
         hipLaunchKernelGGL(k_accumulate_compact, dim3((unsigned)(W * (T / FIX_BLOCK - 1))), dim3(64), 0, st, ends,
                            part_first, W, B, S, T);
     hipLaunchKernelGGL(k_accumulate_fixup, dim3(blocks_for((size_t)W * T, 64)), dim3(64), 0, st, ends, part_first,
-                       part_last, cont_bucket, buckets, long_queue, W, B, S, T);
+                       part_last, cont_bucket, buckets, queue, W, B, S, T);
     const size_t lanes = (size_t)W * T;
     const size_t cap_mid = fixup_queue_cap_mid(lanes) / (64 / MID_G) + 1, cap_long = fixup_queue_cap_long(lanes);
     hipLaunchKernelGGL(k_accumulate_fixup_queue, dim3((unsigned)(cap_mid < 8192 ? cap_mid : 8192)), dim3(64), 0, st, ends,
-                       part_first, part_last, cont_bucket, buckets, long_queue, 1, MID_G, lanes, B, S, T);
+                       part_first, part_last, cont_bucket, buckets, queue, 1, MID_G, lanes, B, S, T);
     hipLaunchKernelGGL(k_accumulate_fixup_queue, dim3((unsigned)(cap_long < 2048 ? cap_long : 2048)), dim3(64), 0, st, ends,
-                       part_first, part_last, cont_bucket, buckets, long_queue, 0, 64u, lanes, B, S, T);
+                       part_first, part_last, cont_bucket, buckets, queue, 0, 64u, lanes, B, S, T);
 }
 void l_reduce_segments(hipStream_t st, const uint32_t* buckets, int W, uint32_t B, uint32_t L, uint32_t* out) {
     hipLaunchKernelGGL(k_reduce_segments, dim3(blocks_for((size_t)W * (B / L), 64)), dim3(64), 0, st, buckets, W, B, L, out);
@@ -1554,8 +1563,8 @@ void l_reduce_segments(hipStream_t st, const uint32_t* buckets, int W, uint32_t 
 void l_sum_butterfly(hipStream_t st, const uint32_t* in, int W, uint32_t M, uint32_t* out) {
     hipLaunchKernelGGL(k_sum_butterfly, dim3(blocks_for((size_t)W * M, 64)), dim3(64), 0, st, in, W, M, out);
 }
-void l_horner(hipStream_t st, const uint32_t* window_sums, int W, int c, int form, uint32_t* out) {
-    hipLaunchKernelGGL(k_horner, dim3(1), dim3(64), 0, st, window_sums, W, c, form, out);
+void l_horner(hipStream_t st, const uint32_t* window_sums, int W, int c, int form, const uint32_t* init, uint32_t* out) {
+    hipLaunchKernelGGL(k_horner, dim3(1), dim3(64), 0, st, window_sums, W, c, form, init, out);
 }
 void l_sum_points(hipStream_t st, const uint32_t* pts, int k, int form, uint32_t* out) {
     hipLaunchKernelGGL(k_sum_points, dim3(1), dim3(64), 0, st, pts, k, form, out);
@@ -1637,7 +1646,7 @@ void l_madd_bench(hipStream_t st, const uint32_t* pts, uint32_t* out, size_t nth
 
 const group_vtable g_vt = {
     GP::CURVE, GP::GROUP, FRW, EW, FR::BITS, GP::LIBFF_PROJECTIVE ? 1 : 0, FR::R,
-    l_import_bases, l_precompute_table, l_count, l_scatter, l_sort, l_accumulate, l_reduce_segments, l_sum_butterfly, l_horner, l_sum_points,
+    l_import_bases, l_precompute_table, l_count, l_scatter, l_sort, l_accumulate, l_accumulate_fixup, l_reduce_segments, l_sum_butterfly, l_horner, l_sum_points,
     l_gen_bases_seq, l_export_affine, l_ffi_decode_points, l_ffi_decode_scalars, l_ffi_encode_point, l_disk_decode, l_fixed_base_exp, l_field_op, l_group_op, l_digits, l_mul_bench, l_madd_bench,
 };
 

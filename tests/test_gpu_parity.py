@@ -9,6 +9,8 @@ Bar: bit-exact.  The MSM result is a group element, so results are compared in a
 form (libff to_affine_coordinates) where the coordinates are canonical field elements;
 field ops and Jacobian group ops are compared limb for limb.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -20,6 +22,7 @@ import libff_amd  # noqa: E402
 from libff_amd import (OUT_AFFINE, OUT_LIBFF, multi_exp_base_form_normal, multi_exp_base_form_special,  # noqa: E402
                        multi_exp_method_BDLO12, multi_exp_method_BDLO12_signed)
 
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 JACOBIAN_GROUPS = [g for g in GROUPS if g[1] != 2]
 
 
@@ -483,3 +486,23 @@ def test_precomputed_multiples_msm(engine, port, name, curve, group, tmp_path):
         for p in (d_tab, d_src, d_sc, d_out):
             engine.free(p)
     assert (out == full).all()
+
+
+def test_window_groups_experimental():
+    """AMDMSM_WINDOW_GROUPS (tails of the high windows on a side stream, engine.cpp): same result.
+    The knob is read once per process, hence the child process."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import libff_amd; from oracle import port\n"
+        "n = 20000; b = port.bases_seq(0, 1, n, first=2); s = port.scalars_sha512(0, 99, n)\n"
+        "e = libff_amd.Engine(0)\n"
+        "got = e.multi_exp(0, 1, b, s, base_form=libff_amd.multi_exp_base_form_special)\n"
+        "want = port.multi_exp(0, 1, b, s, port.BDLO12_SIGNED, 1, chunks=8, omp=True)\n"
+        "assert (got == want).all(); print('groups-ok')\n"
+    ) % (REPO, os.path.join(REPO, "tests"))
+    for groups in ("2", "3"):
+        env = dict(os.environ, AMDMSM_WINDOW_GROUPS=groups)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "groups-ok" in r.stdout, r.stderr[-2000:]
