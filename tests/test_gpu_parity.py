@@ -263,6 +263,20 @@ def test_skewed_scalars(engine, port, name, curve, group):
     assert (engine.multi_exp(curve, group, bases, same, base_form=multi_exp_base_form_special) == want).all()
 
 
+def test_widest_windows(engine, port):
+    """c = 21, 22 (the widest the LDS sort handles: 11 fine bits) and c = 23, 24 (global-atomic
+    histogram + scatter fallback, 2^23 buckets per window), against the oracle."""
+    curve, group, n = 0, 1, 3000
+    bases = port.bases_seq(curve, group, n, first=4)
+    sc = port.scalars_sha512(curve, 1234, n)
+    want = port.multi_exp(curve, group, bases, sc, port.BDLO12_SIGNED, 1, chunks=4, omp=True)
+    for c in (21, 22, 23, 24):
+        got = engine.multi_exp(curve, group, bases, sc, base_form=multi_exp_base_form_special, window_bits=c)
+        assert (got == want).all(), c
+    with pytest.raises(libff_amd.AmdMsmError):
+        engine.multi_exp(curve, group, bases, sc, base_form=multi_exp_base_form_special, window_bits=25)
+
+
 def test_heavy_hitter_buckets_large(engine, port):
     """2^18 points where 70% of the scalars (then all of them) are one repeated value: every
     window has one coarse sort bin far above the cooperative-sort threshold and one bucket
