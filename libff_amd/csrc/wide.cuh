@@ -1,0 +1,196 @@
+// Lane-split prime-field arithmetic for latency-bound chains (the Horner doublings between
+// windows, multiexp.tcc:612-629): one field element per 16-lane DPP row, one 32-bit limb per
+// lane, so a Montgomery product is N short steps of two v_mad_u64_u32 instead of ~2 N^2 of them
+// in one lane, and the four rows of a wave carry four independent products at once.
+//
+// A "quad" is a uint32_t per lane: lane (row, j) holds limb j of the row's element, 0 for j >= N.
+// Cross-lane traffic is DPP only (verified on gfx950 with tools/dpp_probe.hip):
+//   row_newbcast:i  every lane of a row reads the row's lane i
+//   row_shl:1       lane j reads lane j+1 (the row's last lane reads 0 with bound_ctrl)
+//   row_shr:1       lane j reads lane j-1 (the row's first lane reads 0 with bound_ctrl)
+// Carries between limbs are resolved with wave-wide generate/propagate masks (__ballot) and one
+// 64-bit scalar addition; rows cannot leak into each other because lanes j >= N neither
+// generate nor propagate.  Requires N < 16.  All 64 lanes must be active.
+#pragma once
+#include "fp.cuh"
+
+namespace amdmsm {
+
+template <class P>
+struct WideEnv {
+    static_assert(P::N < 16, "one element per 16-lane row");
+    uint32_t j;         // limb index of this lane inside its row
+    uint32_t pj;        // modulus limb (0 for j >= N)
+    bool valid;         // j < N
+};
+
+template <class P>
+AMDMSM_DEV WideEnv<P> wide_env() {
+    WideEnv<P> e;
+    e.j = threadIdx.x & 15u;
+    e.valid = e.j < (uint32_t)P::N;
+    uint32_t pj = 0;
+#pragma unroll
+    for (int i = 0; i < P::N; ++i) pj = (e.j == (uint32_t)i) ? P::P[i] : pj;
+    e.pj = pj;
+    return e;
+}
+
+template <int I>
+AMDMSM_DEV uint32_t row_bcast(uint32_t x) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x150 + I, 0xf, 0xf, false);
+}
+AMDMSM_DEV uint32_t row_down1(uint32_t x) {   // lane j <- lane j+1, last lane of the row <- 0
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x101, 0xf, 0xf, true);
+}
+AMDMSM_DEV uint32_t row_up1(uint32_t x) {     // lane j <- lane j-1, first lane of the row <- 0
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true);
+}
+
+// bit i = carry (borrow) into lane i, given which lanes generate one and which pass one on
+AMDMSM_DEV unsigned long long carry_in_mask(bool gen, bool prop) {
+    const unsigned long long g = __ballot(gen), a = g | __ballot(prop);
+    return (a + g) ^ a ^ g;
+}
+// the carry that left limb N-1 of each row (it sits in the row's lane N), spread over the row
+template <class P>
+AMDMSM_DEV bool row_carry_out(unsigned long long cin) {
+    unsigned long long m = (cin >> P::N) & 0x0001000100010001ull;
+    m |= m << 1;
+    m |= m << 2;
+    m |= m << 4;
+    m |= m << 8;
+    return __builtin_amdgcn_inverse_ballot_w64(m);
+}
+
+// s (limbs of a value < 2p, exact) -> s mod p
+template <class P>
+AMDMSM_DEV uint32_t wide_cond_sub_p(const WideEnv<P>& e, uint32_t s) {
+    uint32_t d = s - e.pj;
+    const unsigned long long bin = carry_in_mask(s < e.pj, e.valid && s == e.pj);
+    d -= __builtin_amdgcn_inverse_ballot_w64(bin) ? 1u : 0u;
+    return row_carry_out<P>(bin) ? s : d;   // borrow out of the top limb: s < p
+}
+
+template <class P>
+AMDMSM_DEV uint32_t wide_add(const WideEnv<P>& e, uint32_t a, uint32_t b) {
+    uint32_t s = a + b;
+    const unsigned long long cin = carry_in_mask(s < a, s == 0xffffffffu);
+    s += __builtin_amdgcn_inverse_ballot_w64(cin) ? 1u : 0u;
+    return wide_cond_sub_p<P>(e, s);
+}
+
+template <class P>
+AMDMSM_DEV uint32_t wide_sub(const WideEnv<P>& e, uint32_t a, uint32_t b) {
+    uint32_t d = a - b;
+    const unsigned long long bin = carry_in_mask(a < b, e.valid && a == b);
+    d -= __builtin_amdgcn_inverse_ballot_w64(bin) ? 1u : 0u;
+    // a < b: add p back (the carry out of the top limb cancels the borrow)
+    uint32_t s = d + e.pj;
+    const unsigned long long cin = carry_in_mask(s < d, e.valid && s == 0xffffffffu);
+    s += __builtin_amdgcn_inverse_ballot_w64(cin) ? 1u : 0u;
+    s = e.valid ? s : 0u;
+    return row_carry_out<P>(bin) ? s : d;
+}
+
+template <class P>
+AMDMSM_DEV uint32_t wide_dbl(const WideEnv<P>& e, uint32_t a) { return wide_add<P>(e, a, a); }
+
+// Montgomery product a * b * 2^(-32 N) mod p, row by row (CIOS; fp.tcc:177-263 computes the
+// same value).  After step i lane j holds column j of (T + a*b_i + m*p) / 2^32 in t and the
+// overflow of that column, still to be added to column j+1, in k.
+template <class P>
+AMDMSM_DEV uint32_t wide_mul(const WideEnv<P>& e, uint32_t a, uint32_t b) {
+    uint32_t t = 0, k = 0;
+    auto step = [&](uint32_t bi) {
+        const unsigned long long A = (unsigned long long)a * bi + t;
+        const uint32_t m = row_bcast<0>((uint32_t)A * P::INV);
+        const unsigned long long B = (unsigned long long)m * e.pj + (uint32_t)A;
+        const unsigned long long s = (A >> 32) + (B >> 32) + k + row_down1((uint32_t)B);
+        t = (uint32_t)s;
+        k = (uint32_t)(s >> 32);
+    };
+    // b_i for a compile-time i
+    step(row_bcast<0>(b));
+    if (P::N > 1) step(row_bcast<1>(b));
+    if (P::N > 2) step(row_bcast<2>(b));
+    if (P::N > 3) step(row_bcast<3>(b));
+    if (P::N > 4) step(row_bcast<4>(b));
+    if (P::N > 5) step(row_bcast<5>(b));
+    if (P::N > 6) step(row_bcast<6>(b));
+    if (P::N > 7) step(row_bcast<7>(b));
+    if (P::N > 8) step(row_bcast<8>(b));
+    if (P::N > 9) step(row_bcast<9>(b));
+    if (P::N > 10) step(row_bcast<10>(b));
+    if (P::N > 11) step(row_bcast<11>(b));
+    if (P::N > 12) step(row_bcast<12>(b));
+    if (P::N > 13) step(row_bcast<13>(b));
+    if (P::N > 14) step(row_bcast<14>(b));
+    // fold the pending overflows into their columns, then one conditional subtraction
+    const uint32_t kk = row_up1(k);
+    uint32_t s = t + kk;
+    const unsigned long long cin = carry_in_mask(s < t, s == 0xffffffffu);
+    s += __builtin_amdgcn_inverse_ballot_w64(cin) ? 1u : 0u;
+    return wide_cond_sub_p<P>(e, s);
+}
+
+// packed (every lane holds the whole element) <-> quad (every row holds the element)
+template <class P, bool I>
+AMDMSM_DEV uint32_t wide_from_packed(const WideEnv<P>& e, const Fp<P, I>& x) {
+    uint32_t w = 0;
+#pragma unroll
+    for (int i = 0; i < P::N; ++i) w = (e.j == (uint32_t)i) ? x.v[i] : w;
+    return w;
+}
+template <class P, bool I>
+AMDMSM_DEV void wide_to_packed(Fp<P, I>& x, uint32_t w) {
+    x.v[0] = row_bcast<0>(w);
+    if (P::N > 1) x.v[1 % P::N] = row_bcast<1>(w);
+    if (P::N > 2) x.v[2 % P::N] = row_bcast<2>(w);
+    if (P::N > 3) x.v[3 % P::N] = row_bcast<3>(w);
+    if (P::N > 4) x.v[4 % P::N] = row_bcast<4>(w);
+    if (P::N > 5) x.v[5 % P::N] = row_bcast<5>(w);
+    if (P::N > 6) x.v[6 % P::N] = row_bcast<6>(w);
+    if (P::N > 7) x.v[7 % P::N] = row_bcast<7>(w);
+    if (P::N > 8) x.v[8 % P::N] = row_bcast<8>(w);
+    if (P::N > 9) x.v[9 % P::N] = row_bcast<9>(w);
+    if (P::N > 10) x.v[10 % P::N] = row_bcast<10>(w);
+    if (P::N > 11) x.v[11 % P::N] = row_bcast<11>(w);
+    if (P::N > 12) x.v[12 % P::N] = row_bcast<12>(w);
+    if (P::N > 13) x.v[13 % P::N] = row_bcast<13>(w);
+    if (P::N > 14) x.v[14 % P::N] = row_bcast<14>(w);
+}
+
+// the element of row r, copied to every row
+AMDMSM_DEV uint32_t from_row(uint32_t w, int r) { return (uint32_t)__shfl((int)w, r * 16 + (int)(threadIdx.x & 15u), 64); }
+
+// Jacobian doubling, a = 0 (dbl-2009-l, the formulas of alt_bn128_g1.cpp:293-335), on a point
+// whose coordinates are quads replicated in every row; the independent products of a stage sit
+// in different rows.  Same value as jac_dbl (ec.cuh).
+template <class P>
+AMDMSM_DEV void jac_dbl_wide(const WideEnv<P>& e, uint32_t& X, uint32_t& Y, uint32_t& Z) {
+    const uint32_t row = (threadIdx.x & 63u) >> 4;
+    // stage 1:  row 0: XX = X^2   row 1: B = Y^2   row 2: YZ = Y*Z
+    uint32_t u = row == 0 ? X : Y;
+    uint32_t v = row == 0 ? X : (row == 1 ? Y : Z);
+    uint32_t r = wide_mul<P>(e, u, v);
+    const uint32_t XX = from_row(r, 0), B = from_row(r, 1), YZ = from_row(r, 2);
+    const uint32_t E3 = wide_add<P>(e, wide_dbl<P>(e, XX), XX);   // E = 3*XX
+    const uint32_t XB = wide_add<P>(e, X, B);
+    // stage 2:  row 0: C = B^2   row 1: (X+B)^2   row 2: F = E^2
+    u = row == 0 ? B : (row == 1 ? XB : E3);
+    r = wide_mul<P>(e, u, u);
+    uint32_t C = from_row(r, 0), D = from_row(r, 1);
+    const uint32_t F = from_row(r, 2);
+    D = wide_sub<P>(e, D, XX);
+    D = wide_sub<P>(e, D, C);
+    D = wide_dbl<P>(e, D);                                         // D = 2((X+B)^2 - XX - C)
+    X = wide_sub<P>(e, F, wide_dbl<P>(e, D));                      // X3 = F - 2D
+    // stage 3: E*(D - X3)
+    const uint32_t t = wide_mul<P>(e, E3, wide_sub<P>(e, D, X));
+    C = wide_dbl<P>(e, wide_dbl<P>(e, wide_dbl<P>(e, C)));         // 8C
+    Y = wide_sub<P>(e, t, C);
+    Z = wide_dbl<P>(e, YZ);
+}
+
+}  // namespace amdmsm
