@@ -962,32 +962,45 @@ __global__ void __launch_bounds__(64) k_sum_butterfly(const uint32_t* __restrict
     if (valid && (i % G) == 0) store_jac(out + (w * (M / G) + i / G) * XYZW, p);
 }
 
-// Horner over the window sums, high to low, c doublings between windows
-// (multiexp.tcc:612-629).  One wave; every lane carries the same running point so the
-// doublings can borrow lanes 0..2 for their field products (jac_dbl_lanes3).
-// c doublings of a point every lane of the wave holds.  Prime-field groups with N < 16 limbs
-// spread each coordinate over the lanes of a DPP row (wide.cuh: ~3x fewer dependent
-// instructions per doubling); the others share the products of a doubling among three lanes.
+// Horner over the window sums, high to low, c doublings between windows (multiexp.tcc:612-629),
+// by one wave.  Prime-field groups with N < 16 limbs run the whole chain on lane-split
+// coordinates (wide.cuh: one limb per lane, four products per step in the four DPP rows, ~3x
+// fewer dependent instructions per doubling); the others share the products of a doubling
+// among three lanes (jac_dbl_lanes3) with every lane holding the running point.
+// init: running value handed over by the windows above this group (may be null).
 template <class P, bool I>
-AMDMSM_DEV typename std::enable_if<(P::N < 16), void>::type horner_doublings(Jac<Fp<P, I>>& res, int c) {
-    if (jac_is_inf(res)) return;   // wave-uniform
+AMDMSM_DEV typename std::enable_if<(P::N < 16), void>::type horner_chain(Jac<Fp<P, I>>& res,
+                                                                         const uint32_t* __restrict__ window_sums, int W,
+                                                                         int c, const uint32_t* __restrict__ init) {
     const WideEnv<P> env = wide_env<P>();
-    uint32_t X = wide_from_packed(env, res.x), Y = wide_from_packed(env, res.y), Z = wide_from_packed(env, res.z);
-    for (int i = 0; i < c; ++i) jac_dbl_wide<P>(env, X, Y, Z);
+    auto load = [&](const uint32_t* p, uint32_t& X, uint32_t& Y, uint32_t& Z) {
+        X = env.valid ? p[env.j] : 0u;
+        Y = env.valid ? p[EW + env.j] : 0u;
+        Z = env.valid ? p[2 * EW + env.j] : 0u;
+    };
+    uint32_t X, Y, Z, X2, Y2, Z2;
+    int w = W - 1;
+    if (init) {
+        load(init, X, Y, Z);
+    } else {
+        load(window_sums + (size_t)w * XYZW, X, Y, Z);
+        --w;
+    }
+    for (; w >= 0; --w) {
+        if (!wide_is_zero(Z)) {
+            for (int i = 0; i < c; ++i) jac_dbl_wide<P>(env, X, Y, Z);
+        }
+        load(window_sums + (size_t)w * XYZW, X2, Y2, Z2);
+        jac_add_wide<P>(env, X, Y, Z, X2, Y2, Z2);
+    }
     wide_to_packed(res.x, X);
     wide_to_packed(res.y, Y);
     wide_to_packed(res.z, Z);
 }
 template <class EE>
-AMDMSM_DEV void horner_doublings(Jac<EE>& res, int c, ...) {
-    for (int i = 0; i < c; ++i) jac_dbl_lanes3(res);
-}
-
-__global__ void __launch_bounds__(64) k_horner(const uint32_t* __restrict__ window_sums, int W, int c, int form,
-                                               const uint32_t* __restrict__ init, uint32_t* __restrict__ out) {
-    // init: running value handed over by the windows above this group (they are combined on
-    // another stream while the windows of this group are still being accumulated)
-    Jac<E> res, x;
+AMDMSM_DEV void horner_chain(Jac<EE>& res, const uint32_t* __restrict__ window_sums, int W, int c,
+                             const uint32_t* __restrict__ init, ...) {
+    Jac<EE> x;
     int w = W - 1;
     if (init) {
         load_jac(res, init);
@@ -996,10 +1009,16 @@ __global__ void __launch_bounds__(64) k_horner(const uint32_t* __restrict__ wind
         --w;
     }
     for (; w >= 0; --w) {
-        horner_doublings(res, c);
+        for (int i = 0; i < c; ++i) jac_dbl_lanes3(res);
         load_jac(x, window_sums + (size_t)w * XYZW);
         jac_add(res, res, x);
     }
+}
+
+__global__ void __launch_bounds__(64) k_horner(const uint32_t* __restrict__ window_sums, int W, int c, int form,
+                                               const uint32_t* __restrict__ init, uint32_t* __restrict__ out) {
+    Jac<E> res;
+    horner_chain(res, window_sums, W, c, init);
     if (threadIdx.x == 0) store_out(out, res, form);
 }
 

@@ -193,4 +193,49 @@ AMDMSM_DEV void jac_dbl_wide(const WideEnv<P>& e, uint32_t& X, uint32_t& Y, uint
     Z = wide_dbl<P>(e, YZ);
 }
 
+// wave-uniform test of a quad that every row holds a copy of
+AMDMSM_DEV bool wide_is_zero(uint32_t w) { return __ballot(w != 0u) == 0ull; }
+
+// General Jacobian addition (add-2007-bl with Z3 = 2*Z1*Z2*H, the product sequence of jac_add in
+// ec.cuh / alt_bn128_g1.cpp:134-206), sixteen products in five stages of up to four rows.
+// Points at infinity and P == Q are resolved here (wave-uniform branches); P == -Q falls out
+// of the formulas as Z3 = 0.
+template <class P>
+AMDMSM_DEV void jac_add_wide(const WideEnv<P>& e, uint32_t& X1, uint32_t& Y1, uint32_t& Z1, uint32_t X2, uint32_t Y2,
+                             uint32_t Z2) {
+    if (wide_is_zero(Z2)) return;
+    if (wide_is_zero(Z1)) {
+        X1 = X2;
+        Y1 = Y2;
+        Z1 = Z2;
+        return;
+    }
+    const uint32_t row = (threadIdx.x & 63u) >> 4;
+    const bool r0 = row == 0, r1 = row == 1, r2 = row == 2;
+    // stage 1:  Z1^2 | Z2^2 | Z1*Z2
+    uint32_t r = wide_mul<P>(e, r1 ? Z2 : Z1, r0 ? Z1 : Z2);
+    const uint32_t z1z1 = from_row(r, 0), z2z2 = from_row(r, 1), z1z2 = from_row(r, 2);
+    // stage 2:  U1 = X1*Z2Z2 | U2 = X2*Z1Z1 | Z2*Z2Z2 | Z1*Z1Z1
+    r = wide_mul<P>(e, r0 ? X1 : (r1 ? X2 : (r2 ? Z2 : Z1)), (r0 || r2) ? z2z2 : z1z1);
+    const uint32_t u1 = from_row(r, 0), u2 = from_row(r, 1), t1 = from_row(r, 2), t2 = from_row(r, 3);
+    const uint32_t h = wide_sub<P>(e, u2, u1), h2 = wide_dbl<P>(e, h);
+    // stage 3:  S1 = Y1*Z2^3 | S2 = Y2*Z1^3 | I = (2H)^2 | Z1*Z2*H
+    r = wide_mul<P>(e, r0 ? Y1 : (r1 ? Y2 : (r2 ? h2 : z1z2)), r0 ? t1 : (r1 ? t2 : (r2 ? h2 : h)));
+    const uint32_t s1 = from_row(r, 0), s2 = from_row(r, 1), ii = from_row(r, 2), zh = from_row(r, 3);
+    const uint32_t rr = wide_dbl<P>(e, wide_sub<P>(e, s2, s1));
+    if (wide_is_zero(h) && wide_is_zero(rr)) {   // the same point: double it
+        jac_dbl_wide<P>(e, X1, Y1, Z1);
+        return;
+    }
+    // stage 4:  J = H*I | V = U1*I | r^2
+    r = wide_mul<P>(e, r0 ? h : (r1 ? u1 : rr), r2 ? rr : ii);
+    const uint32_t J = from_row(r, 0), V = from_row(r, 1), R2 = from_row(r, 2);
+    X1 = wide_sub<P>(e, wide_sub<P>(e, wide_sub<P>(e, R2, J), V), V);     // X3 = r^2 - J - 2V
+    // stage 5:  r*(V - X3) | S1*J
+    r = wide_mul<P>(e, r0 ? rr : s1, r0 ? wide_sub<P>(e, V, X1) : J);
+    const uint32_t sj = from_row(r, 1);
+    Y1 = wide_sub<P>(e, wide_sub<P>(e, from_row(r, 0), sj), sj);          // Y3 = r(V - X3) - 2 S1 J
+    Z1 = wide_dbl<P>(e, zh);                                              // Z3 = 2 Z1 Z2 H
+}
+
 }  // namespace amdmsm

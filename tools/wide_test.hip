@@ -12,7 +12,7 @@
 
 using namespace amdmsm;
 
-// in: per test 4 rows x (a, b, c) packed (N words each).  out: per test 4 rows x 7 results.
+// in: per test 4 rows x (a, b, c) packed (N words each).  out: per test 4 rows x 10 results.
 template <class P>
 __global__ void __launch_bounds__(64) k_test(const uint32_t* in, uint32_t* out_wide, uint32_t* out_ref, int tests) {
     constexpr int N = P::N;
@@ -21,7 +21,7 @@ __global__ void __launch_bounds__(64) k_test(const uint32_t* in, uint32_t* out_w
     for (int t = 0; t < tests; ++t) {
         const uint32_t* base = in + ((size_t)t * 4 + row) * 3 * N;
         const uint32_t a = j < N ? base[j] : 0u, b = j < N ? base[N + j] : 0u, c = j < N ? base[2 * N + j] : 0u;
-        uint32_t res[7];
+        uint32_t res[10];
         res[0] = wide_mul<P>(e, a, b);
         res[1] = wide_add<P>(e, a, b);
         res[2] = wide_sub<P>(e, a, b);
@@ -32,8 +32,26 @@ __global__ void __launch_bounds__(64) k_test(const uint32_t* in, uint32_t* out_w
         res[4] = X;
         res[5] = Y;
         res[6] = Z;
-        for (int q = 0; q < 7; ++q)
-            if (j < N) out_wide[(((size_t)t * 4 + row) * 7 + q) * N + j] = res[q];
+        // (row 0's a, b, c) + (row 1's a, b, c); every 16th test adds a point to itself, every
+        // 16th + 1 to its negative, every 16th + 2 to infinity
+        {
+            uint32_t X1 = from_row(a, 0), Y1 = from_row(b, 0), Z1 = from_row(c, 0);
+            uint32_t X2 = from_row(a, 1), Y2 = from_row(b, 1), Z2 = from_row(c, 1);
+            if (t % 16 == 0 || t % 16 == 1) {
+                X2 = X1;
+                Y2 = Y1;
+                Z2 = Z1;
+            }
+            if (t % 16 == 1) Y2 = wide_sub<P>(e, 0u, Y2);
+            if (t % 16 == 2) Z2 = 0;
+            if (t % 16 == 3) Z1 = 0;
+            jac_add_wide<P>(e, X1, Y1, Z1, X2, Y2, Z2);
+            res[7] = X1;
+            res[8] = Y1;
+            res[9] = Z1;
+        }
+        for (int q = 0; q < 10; ++q)
+            if (j < N) out_wide[(((size_t)t * 4 + row) * 10 + q) * N + j] = res[q];
         // reference: lane r (< 4) does row r with the per-lane code
         if (lane < 4) {
             const uint32_t* bs = in + ((size_t)t * 4 + lane) * 3 * N;
@@ -42,7 +60,7 @@ __global__ void __launch_bounds__(64) k_test(const uint32_t* in, uint32_t* out_w
                 fa.v[i] = bs[i];
                 fb.v[i] = bs[N + i];
             }
-            uint32_t* o = out_ref + ((size_t)t * 4 + lane) * 7 * N;
+            uint32_t* o = out_ref + ((size_t)t * 4 + lane) * 10 * N;
             fp_mul(r, fa, fb);
             for (int i = 0; i < N; ++i) o[i] = r.v[i];
             fp_add(r, fa, fb);
@@ -63,6 +81,26 @@ __global__ void __launch_bounds__(64) k_test(const uint32_t* in, uint32_t* out_w
                 o[4 * N + i] = pt.x.v[i];
                 o[5 * N + i] = pt.y.v[i];
                 o[6 * N + i] = pt.z.v[i];
+            }
+            Jac<Fp<P, false>> p1, p2;
+            const uint32_t* b1 = b0 + 3 * N;
+            for (int i = 0; i < N; ++i) {
+                p1.x.v[i] = b0[i];
+                p1.y.v[i] = b0[N + i];
+                p1.z.v[i] = b0[2 * N + i];
+                p2.x.v[i] = b1[i];
+                p2.y.v[i] = b1[N + i];
+                p2.z.v[i] = b1[2 * N + i];
+            }
+            if (t % 16 == 0 || t % 16 == 1) p2 = p1;
+            if (t % 16 == 1) fp_neg(p2.y, p2.y);
+            if (t % 16 == 2) fp_set_zero(p2.z);
+            if (t % 16 == 3) fp_set_zero(p1.z);
+            jac_add(p1, p1, p2);
+            for (int i = 0; i < N; ++i) {
+                o[7 * N + i] = p1.x.v[i];
+                o[8 * N + i] = p1.y.v[i];
+                o[9 * N + i] = p1.z.v[i];
             }
         }
     }
@@ -94,7 +132,7 @@ int run(const char* name) {
         if (kind != 2) in[e * N + N - 1] %= P::P[N - 1];
     }
     uint32_t *d_in, *d_w, *d_r;
-    const size_t ob = (size_t)tests * 4 * 7 * N * 4;
+    const size_t ob = (size_t)tests * 4 * 10 * N * 4;
     hipMalloc(&d_in, in.size() * 4);
     hipMalloc(&d_w, ob);
     hipMalloc(&d_r, ob);
@@ -105,16 +143,16 @@ int run(const char* name) {
     std::vector<uint32_t> w(ob / 4), r(ob / 4);
     hipMemcpy(w.data(), d_w, ob, hipMemcpyDeviceToHost);
     hipMemcpy(r.data(), d_r, ob, hipMemcpyDeviceToHost);
-    const char* ops[7] = {"mul", "add", "sub", "dbl", "jdbl.X", "jdbl.Y", "jdbl.Z"};
-    int bad[7] = {};
+    const char* ops[10] = {"mul", "add", "sub", "dbl", "jdbl.X", "jdbl.Y", "jdbl.Z", "jadd.X", "jadd.Y", "jadd.Z"};
+    int bad[10] = {};
     for (int t = 0; t < tests; ++t)
         for (int row = 0; row < 4; ++row)
-            for (int q = 0; q < 7; ++q) {
-                const size_t o = (((size_t)t * 4 + row) * 7 + q) * N;
+            for (int q = 0; q < 10; ++q) {
+                const size_t o = (((size_t)t * 4 + row) * 10 + q) * N;
                 bool same = true;
                 for (int i = 0; i < N; ++i) same = same && w[o + i] == r[o + i];
-                if (q == 4 || q == 5) {   // the point at infinity (Z = 0) is left alone by jac_dbl: X, Y are free
-                    const size_t oz = (((size_t)t * 4 + row) * 7 + 6) * N;
+                if (q == 4 || q == 5 || q == 7 || q == 8) {   // a result at infinity (Z = 0): X, Y are free
+                    const size_t oz = (((size_t)t * 4 + row) * 10 + (q < 7 ? 6 : 9)) * N;
                     bool zinf = true;
                     for (int i = 0; i < N; ++i) zinf = zinf && r[oz + i] == 0;
                     same = same || zinf;
@@ -130,9 +168,9 @@ int run(const char* name) {
                 }
             }
     int total = 0;
-    for (int q = 0; q < 7; ++q) total += bad[q];
+    for (int q = 0; q < 10; ++q) total += bad[q];
     printf("%s: %d tests x 4 rows:", name, tests);
-    for (int q = 0; q < 7; ++q) printf(" %s=%s", ops[q], bad[q] ? "FAIL" : "ok");
+    for (int q = 0; q < 10; ++q) printf(" %s=%s", ops[q], bad[q] ? "FAIL" : "ok");
     printf("\n");
     return total;
 }
