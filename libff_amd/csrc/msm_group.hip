@@ -997,6 +997,42 @@ AMDMSM_DEV typename std::enable_if<(P::N < 16), void>::type horner_chain(Jac<Fp<
     wide_to_packed(res.y, Y);
     wide_to_packed(res.z, Z);
 }
+// Fq2 groups: c0 / c1 in alternating rows, the three Karatsuba products of a multiplication side
+// by side (WideFq2)
+template <class P, int NR, bool I>
+AMDMSM_DEV typename std::enable_if<(P::N < 16), void>::type horner_chain(Jac<Fp2<P, NR, I>>& res,
+                                                                         const uint32_t* __restrict__ window_sums, int W,
+                                                                         int c, const uint32_t* __restrict__ init) {
+    using F = WideFq2<P, NR>;
+    const WideEnv<P> env = wide_env<P>();
+    const uint32_t wi = F::word_index(env);
+    auto load = [&](const uint32_t* p, uint32_t& X, uint32_t& Y, uint32_t& Z) {
+        X = env.valid ? p[wi] : 0u;
+        Y = env.valid ? p[EW + wi] : 0u;
+        Z = env.valid ? p[2 * EW + wi] : 0u;
+    };
+    uint32_t X, Y, Z, X2, Y2, Z2;
+    int w = W - 1;
+    if (init) {
+        load(init, X, Y, Z);
+    } else {
+        load(window_sums + (size_t)w * XYZW, X, Y, Z);
+        --w;
+    }
+    for (; w >= 0; --w) {
+        if (!wide_is_zero(Z)) {
+            for (int i = 0; i < c; ++i) jac_dbl_seq<F, P>(env, X, Y, Z);
+        }
+        load(window_sums + (size_t)w * XYZW, X2, Y2, Z2);
+        jac_add_seq<F, P>(env, X, Y, Z, X2, Y2, Z2);
+    }
+    wide_to_packed(res.x.c0, from_row(X, 0));
+    wide_to_packed(res.x.c1, from_row(X, 1));
+    wide_to_packed(res.y.c0, from_row(Y, 0));
+    wide_to_packed(res.y.c1, from_row(Y, 1));
+    wide_to_packed(res.z.c0, from_row(Z, 0));
+    wide_to_packed(res.z.c1, from_row(Z, 1));
+}
 template <class EE>
 AMDMSM_DEV void horner_chain(Jac<EE>& res, const uint32_t* __restrict__ window_sums, int W, int c,
                              const uint32_t* __restrict__ init, ...) {

@@ -238,4 +238,85 @@ AMDMSM_DEV void jac_add_wide(const WideEnv<P>& e, uint32_t& X1, uint32_t& Y1, ui
     Z1 = wide_dbl<P>(e, zh);                                              // Z3 = 2 Z1 Z2 H
 }
 
+// ---------------------------------------------------------------- Fq2 = Fq[u]/(u^2 - NR)
+// A quad holds one Fq2 element: c0 in rows 0 and 2, c1 in rows 1 and 3, so additions and
+// subtractions are single quad operations and the three products of a Karatsuba
+// multiplication (fp2.tcc:100-118) run in rows 0, 1 and 2 of one wide_mul.
+AMDMSM_DEV uint32_t row_swap(uint32_t w) { return (uint32_t)__shfl_xor((int)w, 16, 64); }   // c0 <-> c1
+
+template <class P, int NR>
+struct WideFq2 {
+    static_assert(NR == -1 || NR == -5, "unsupported non-residue");
+    // (c0, c1) from the products v0 = a0 b0, v1 = a1 b1, v2 = (a0 + a1)(b0 + b1), each replicated
+    static AMDMSM_DEV uint32_t combine(const WideEnv<P>& e, uint32_t v0, uint32_t v1, uint32_t v2) {
+        const bool odd = ((threadIdx.x >> 4) & 1u) != 0;
+        uint32_t t = v1;                                    // |NR| * v1
+        if (NR == -5) t = wide_add<P>(e, wide_dbl<P>(e, wide_dbl<P>(e, v1)), v1);
+        uint32_t x = wide_sub<P>(e, odd ? v2 : v0, odd ? v0 : t);   // c0 = v0 + NR v1 | v2 - v0
+        return wide_sub<P>(e, x, odd ? v1 : 0u);                    //                 | - v1
+    }
+    static AMDMSM_DEV uint32_t mul(const WideEnv<P>& e, uint32_t a, uint32_t b) {
+        const bool r2 = ((threadIdx.x & 63u) >> 4) == 2;
+        const uint32_t sa = wide_add<P>(e, a, row_swap(a)), sb = wide_add<P>(e, b, row_swap(b));
+        const uint32_t r = wide_mul<P>(e, r2 ? sa : a, r2 ? sb : b);   // a0 b0 | a1 b1 | (a0+a1)(b0+b1) | a1 b1
+        return combine(e, from_row(r, 0), from_row(r, 1), from_row(r, 2));
+    }
+    static AMDMSM_DEV uint32_t sqr(const WideEnv<P>& e, uint32_t a) {
+        if (NR != -1) return mul(e, a, a);
+        // complex squaring (fp2.tcc:141-151): c0 = (a0 + a1)(a0 - a1), c1 = 2 a0 a1
+        const uint32_t row = (threadIdx.x & 63u) >> 4;
+        const uint32_t sw = row_swap(a);
+        const uint32_t s = wide_add<P>(e, a, sw), d = wide_sub<P>(e, a, sw);   // even rows of d: a0 - a1
+        const uint32_t r = wide_mul<P>(e, row == 2 ? s : a, row == 2 ? d : sw);   // row 0: a0 a1, row 2: c0
+        const uint32_t c0 = from_row(r, 2), v = from_row(r, 0);
+        return (row & 1u) ? wide_dbl<P>(e, v) : c0;
+    }
+    static AMDMSM_DEV uint32_t add(const WideEnv<P>& e, uint32_t a, uint32_t b) { return wide_add<P>(e, a, b); }
+    static AMDMSM_DEV uint32_t sub(const WideEnv<P>& e, uint32_t a, uint32_t b) { return wide_sub<P>(e, a, b); }
+    static AMDMSM_DEV uint32_t dbl(const WideEnv<P>& e, uint32_t a) { return wide_add<P>(e, a, a); }
+    // word of a packed Fq2 coordinate this lane holds
+    static AMDMSM_DEV uint32_t word_index(const WideEnv<P>& e) { return ((threadIdx.x >> 4) & 1u) * P::N + e.j; }
+};
+
+// The same Jacobian formulas as jac_dbl_wide / jac_add_wide, one product after the other, over
+// any quad field F (used for Fq2, whose products already fill the rows).
+template <class F, class P>
+AMDMSM_DEV void jac_dbl_seq(const WideEnv<P>& e, uint32_t& X, uint32_t& Y, uint32_t& Z) {
+    const uint32_t XX = F::sqr(e, X), B = F::sqr(e, Y), YZ = F::mul(e, Y, Z);
+    const uint32_t E3 = F::add(e, F::dbl(e, XX), XX);
+    uint32_t C = F::sqr(e, B);
+    uint32_t D = F::sqr(e, F::add(e, X, B));
+    D = F::dbl(e, F::sub(e, F::sub(e, D, XX), C));
+    X = F::sub(e, F::sqr(e, E3), F::dbl(e, D));
+    C = F::dbl(e, F::dbl(e, F::dbl(e, C)));
+    Y = F::sub(e, F::mul(e, E3, F::sub(e, D, X)), C);
+    Z = F::dbl(e, YZ);
+}
+template <class F, class P>
+AMDMSM_DEV void jac_add_seq(const WideEnv<P>& e, uint32_t& X1, uint32_t& Y1, uint32_t& Z1, uint32_t X2, uint32_t Y2,
+                            uint32_t Z2) {
+    if (wide_is_zero(Z2)) return;
+    if (wide_is_zero(Z1)) {
+        X1 = X2;
+        Y1 = Y2;
+        Z1 = Z2;
+        return;
+    }
+    const uint32_t z1z1 = F::sqr(e, Z1), z2z2 = F::sqr(e, Z2);
+    const uint32_t u1 = F::mul(e, X1, z2z2), u2 = F::mul(e, X2, z1z1);
+    const uint32_t s1 = F::mul(e, Y1, F::mul(e, Z2, z2z2)), s2 = F::mul(e, Y2, F::mul(e, Z1, z1z1));
+    const uint32_t h = F::sub(e, u2, u1), rr = F::dbl(e, F::sub(e, s2, s1));
+    if (wide_is_zero(h) && wide_is_zero(rr)) {
+        jac_dbl_seq<F, P>(e, X1, Y1, Z1);
+        return;
+    }
+    const uint32_t ii = F::sqr(e, F::dbl(e, h));
+    const uint32_t J = F::mul(e, h, ii), V = F::mul(e, u1, ii);
+    const uint32_t zh = F::mul(e, F::mul(e, Z1, Z2), h);
+    X1 = F::sub(e, F::sub(e, F::sub(e, F::sqr(e, rr), J), V), V);
+    const uint32_t sj = F::mul(e, s1, J);
+    Y1 = F::sub(e, F::sub(e, F::mul(e, rr, F::sub(e, V, X1)), sj), sj);
+    Z1 = F::dbl(e, zh);
+}
+
 }  // namespace amdmsm

@@ -8,6 +8,7 @@
 
 #include "curve_params.h"
 #include "ec.cuh"
+#include "fp2.cuh"
 #include "wide.cuh"
 
 using namespace amdmsm;
@@ -175,8 +176,143 @@ int run(const char* name) {
     return total;
 }
 
+// Fq2: per test two points (X, Y, Z) of 2N words each; out: mul, sqr of (X1, Y1) and the doubling /
+// addition results
+template <class P, int NR>
+__global__ void __launch_bounds__(64) k_test2(const uint32_t* in, uint32_t* out_wide, uint32_t* out_ref, int tests) {
+    constexpr int N = P::N, EW2 = 2 * N;
+    using F = WideFq2<P, NR>;
+    using E2 = Fp2<P, NR, false>;
+    const WideEnv<P> e = wide_env<P>();
+    const uint32_t lane = threadIdx.x & 63u, row = lane >> 4;
+    const uint32_t wi = F::word_index(e);
+    for (int t = 0; t < tests; ++t) {
+        const uint32_t* b = in + (size_t)t * 6 * EW2;
+        uint32_t q[6];
+        for (int k = 0; k < 6; ++k) q[k] = e.valid ? b[k * EW2 + wi] : 0u;
+        uint32_t res[8];
+        res[0] = F::mul(e, q[0], q[1]);
+        res[1] = F::sqr(e, q[0]);
+        uint32_t X = q[0], Y = q[1], Z = q[2];
+        jac_dbl_seq<F, P>(e, X, Y, Z);
+        res[2] = X;
+        res[3] = Y;
+        res[4] = Z;
+        uint32_t X1 = q[0], Y1 = q[1], Z1 = q[2], X2 = q[3], Y2 = q[4], Z2 = q[5];
+        if (t % 16 == 0 || t % 16 == 1) {
+            X2 = X1;
+            Y2 = Y1;
+            Z2 = Z1;
+        }
+        if (t % 16 == 1) Y2 = F::sub(e, 0u, Y2);
+        if (t % 16 == 2) Z2 = 0;
+        if (t % 16 == 3) Z1 = 0;
+        jac_add_seq<F, P>(e, X1, Y1, Z1, X2, Y2, Z2);
+        res[5] = X1;
+        res[6] = Y1;
+        res[7] = Z1;
+        if (row < 2 && e.valid)
+            for (int k = 0; k < 8; ++k) out_wide[((size_t)t * 8 + k) * EW2 + wi] = res[k];
+        if (lane == 0) {
+            E2 v[6], r;
+            for (int k = 0; k < 6; ++k) el_load(v[k], b + k * EW2);
+            uint32_t* o = out_ref + (size_t)t * 8 * EW2;
+            el_mul(r, v[0], v[1]);
+            el_store(o, r);
+            el_sqr(r, v[0]);
+            el_store(o + EW2, r);
+            Jac<E2> p1, p2;
+            p1.x = v[0];
+            p1.y = v[1];
+            p1.z = v[2];
+            p2 = p1;
+            jac_dbl(p2, p2);
+            el_store(o + 2 * EW2, p2.x);
+            el_store(o + 3 * EW2, p2.y);
+            el_store(o + 4 * EW2, p2.z);
+            p2.x = v[3];
+            p2.y = v[4];
+            p2.z = v[5];
+            if (t % 16 == 0 || t % 16 == 1) p2 = p1;
+            if (t % 16 == 1) el_neg(p2.y, p2.y);
+            if (t % 16 == 2) el_zero(p2.z);
+            if (t % 16 == 3) el_zero(p1.z);
+            jac_add(p1, p1, p2);
+            el_store(o + 5 * EW2, p1.x);
+            el_store(o + 6 * EW2, p1.y);
+            el_store(o + 7 * EW2, p1.z);
+        }
+    }
+}
+
+template <class P, int NR>
+int run2(const char* name) {
+    constexpr int N = P::N, EW2 = 2 * N;
+    const int tests = 1000;
+    std::vector<uint32_t> in((size_t)tests * 6 * EW2);
+    uint64_t s = 0x2545f4914f6cdd1dull;
+    auto rnd = [&]() {
+        s ^= s << 13;
+        s ^= s >> 7;
+        s ^= s << 17;
+        return (uint32_t)(s >> 16);
+    };
+    for (size_t el = 0; el < in.size() / N; ++el) {
+        const int kind = (int)(rnd() % 8);
+        for (int i = 0; i < N; ++i) {
+            uint32_t w = rnd();
+            if (kind == 0) w = 0xffffffffu;
+            if (kind == 1) w = 0;
+            in[el * N + i] = w;
+        }
+        in[el * N + N - 1] %= P::P[N - 1];
+    }
+    uint32_t *d_in, *d_w, *d_r;
+    const size_t ob = (size_t)tests * 8 * EW2 * 4;
+    hipMalloc(&d_in, in.size() * 4);
+    hipMalloc(&d_w, ob);
+    hipMalloc(&d_r, ob);
+    hipMemset(d_w, 0, ob);
+    hipMemset(d_r, 0, ob);
+    hipMemcpy(d_in, in.data(), in.size() * 4, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL((k_test2<P, NR>), dim3(1), dim3(64), 0, 0, d_in, d_w, d_r, tests);
+    std::vector<uint32_t> w(ob / 4), r(ob / 4);
+    hipMemcpy(w.data(), d_w, ob, hipMemcpyDeviceToHost);
+    hipMemcpy(r.data(), d_r, ob, hipMemcpyDeviceToHost);
+    const char* ops[8] = {"mul", "sqr", "jdbl.X", "jdbl.Y", "jdbl.Z", "jadd.X", "jadd.Y", "jadd.Z"};
+    int bad[8] = {};
+    for (int t = 0; t < tests; ++t)
+        for (int q = 0; q < 8; ++q) {
+            const size_t o = ((size_t)t * 8 + q) * EW2;
+            bool same = true;
+            for (int i = 0; i < EW2; ++i) same = same && w[o + i] == r[o + i];
+            if (q == 2 || q == 3 || q == 5 || q == 6) {
+                const size_t oz = ((size_t)t * 8 + (q < 5 ? 4 : 7)) * EW2;
+                bool zinf = true;
+                for (int i = 0; i < EW2; ++i) zinf = zinf && r[oz + i] == 0;
+                same = same || zinf;
+            }
+            if (!same && bad[q]++ == 0) {
+                printf("%s %s first mismatch test %d\n  wide:", name, ops[q], t);
+                for (int i = EW2 - 1; i >= 0; --i) printf(" %08x", w[o + i]);
+                printf("\n  ref: ");
+                for (int i = EW2 - 1; i >= 0; --i) printf(" %08x", r[o + i]);
+                printf("\n");
+            }
+        }
+    int total = 0;
+    printf("%s: %d tests:", name, tests);
+    for (int q = 0; q < 8; ++q) {
+        total += bad[q];
+        printf(" %s=%s", ops[q], bad[q] ? "FAIL" : "ok");
+    }
+    printf("\n");
+    return total;
+}
+
 int main() {
     int bad = run<alt_bn128_fq>("alt_bn128_fq") + run<bls12_377_fq>("bls12_377_fq");
+    bad += run2<alt_bn128_fq, -1>("alt_bn128_fq2") + run2<bls12_377_fq, -5>("bls12_377_fq2");
     printf(bad ? "WIDE TEST FAILED\n" : "WIDE TEST PASSED\n");
     return bad ? 1 : 0;
 }
