@@ -997,6 +997,36 @@ AMDMSM_DEV typename std::enable_if<(P::N < 16), void>::type horner_chain(Jac<Fp<
     wide_to_packed(res.y, Y);
     wide_to_packed(res.z, Z);
 }
+// prime fields of 16..31 limbs (bw6_761): two 32-lane rows, one product at a time
+template <class P, bool I>
+AMDMSM_DEV typename std::enable_if<(P::N >= 16 && P::N < 32), void>::type horner_chain(
+    Jac<Fp<P, I>>& res, const uint32_t* __restrict__ window_sums, int W, int c, const uint32_t* __restrict__ init) {
+    using F = WideFq<P>;
+    const WideEnv<P> env = wide_env<P>();
+    auto load = [&](const uint32_t* p, uint32_t& X, uint32_t& Y, uint32_t& Z) {
+        X = env.valid ? p[env.j] : 0u;
+        Y = env.valid ? p[EW + env.j] : 0u;
+        Z = env.valid ? p[2 * EW + env.j] : 0u;
+    };
+    uint32_t X, Y, Z, X2, Y2, Z2;
+    int w = W - 1;
+    if (init) {
+        load(init, X, Y, Z);
+    } else {
+        load(window_sums + (size_t)w * XYZW, X, Y, Z);
+        --w;
+    }
+    for (; w >= 0; --w) {
+        if (!wide_is_zero(Z)) {
+            for (int i = 0; i < c; ++i) jac_dbl_seq<F, P>(env, X, Y, Z);
+        }
+        load(window_sums + (size_t)w * XYZW, X2, Y2, Z2);
+        jac_add_seq<F, P>(env, X, Y, Z, X2, Y2, Z2);
+    }
+    wide_to_packed(res.x, X);
+    wide_to_packed(res.y, Y);
+    wide_to_packed(res.z, Z);
+}
 // Fq2 groups: c0 / c1 in alternating rows, the three Karatsuba products of a multiplication side
 // by side (WideFq2)
 template <class P, int NR, bool I>

@@ -10,7 +10,9 @@
 //   row_shr:1       lane j reads lane j-1 (the row's first lane reads 0 with bound_ctrl)
 // Carries between limbs are resolved with wave-wide generate/propagate masks (__ballot) and one
 // 64-bit scalar addition; rows cannot leak into each other because lanes j >= N neither
-// generate nor propagate.  Requires N < 16.  All 64 lanes must be active.
+// generate nor propagate.  Fields of 16..31 limbs (bw6_761: 24) use 32-lane rows: two elements
+// per wave, wave_shl / wave_shr for the shifts and v_readlane for the broadcasts.
+// All 64 lanes must be active.
 #pragma once
 #include "fp.cuh"
 
@@ -18,7 +20,8 @@ namespace amdmsm {
 
 template <class P>
 struct WideEnv {
-    static_assert(P::N < 16, "one element per 16-lane row");
+    static_assert(P::N < 32, "one element per 16- or 32-lane row");
+    static constexpr int ROW = P::N < 16 ? 16 : 32;
     uint32_t j;         // limb index of this lane inside its row
     uint32_t pj;        // modulus limb (0 for j >= N)
     bool valid;         // j < N
@@ -27,7 +30,7 @@ struct WideEnv {
 template <class P>
 AMDMSM_DEV WideEnv<P> wide_env() {
     WideEnv<P> e;
-    e.j = threadIdx.x & 15u;
+    e.j = threadIdx.x & (uint32_t)(WideEnv<P>::ROW - 1);
     e.valid = e.j < (uint32_t)P::N;
     uint32_t pj = 0;
 #pragma unroll
@@ -36,15 +39,30 @@ AMDMSM_DEV WideEnv<P> wide_env() {
     return e;
 }
 
-template <int I>
+// every lane of a row reads the row's lane I
+template <class P, int I>
 AMDMSM_DEV uint32_t row_bcast(uint32_t x) {
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x150 + I, 0xf, 0xf, false);
+    if (WideEnv<P>::ROW == 16) {
+        return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x150 + (I & 15), 0xf, 0xf, false);
+    } else {
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)x, I & 31);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)x, 32 + (I & 31));
+        return (threadIdx.x & 32u) ? hi : lo;
+    }
 }
-AMDMSM_DEV uint32_t row_down1(uint32_t x) {   // lane j <- lane j+1, last lane of the row <- 0
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x101, 0xf, 0xf, true);
+// lane j <- lane j+1, last lane of the row <- 0
+template <class P>
+AMDMSM_DEV uint32_t row_down1(const WideEnv<P>& e, uint32_t x) {
+    if (WideEnv<P>::ROW == 16) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x101, 0xf, 0xf, true);
+    const uint32_t v = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x130, 0xf, 0xf, true);   // wave_shl:1
+    return e.j == 31u ? 0u : v;
 }
-AMDMSM_DEV uint32_t row_up1(uint32_t x) {     // lane j <- lane j-1, first lane of the row <- 0
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true);
+// lane j <- lane j-1, first lane of the row <- 0
+template <class P>
+AMDMSM_DEV uint32_t row_up1(const WideEnv<P>& e, uint32_t x) {
+    if (WideEnv<P>::ROW == 16) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true);
+    const uint32_t v = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x138, 0xf, 0xf, true);   // wave_shr:1
+    return e.j == 0u ? 0u : v;
 }
 
 // bit i = carry (borrow) into lane i, given which lanes generate one and which pass one on
@@ -55,11 +73,12 @@ AMDMSM_DEV unsigned long long carry_in_mask(bool gen, bool prop) {
 // the carry that left limb N-1 of each row (it sits in the row's lane N), spread over the row
 template <class P>
 AMDMSM_DEV bool row_carry_out(unsigned long long cin) {
-    unsigned long long m = (cin >> P::N) & 0x0001000100010001ull;
+    unsigned long long m = (cin >> P::N) & (WideEnv<P>::ROW == 16 ? 0x0001000100010001ull : 0x0000000100000001ull);
     m |= m << 1;
     m |= m << 2;
     m |= m << 4;
     m |= m << 8;
+    if (WideEnv<P>::ROW == 32) m |= m << 16;
     return __builtin_amdgcn_inverse_ballot_w64(m);
 }
 
@@ -99,35 +118,26 @@ AMDMSM_DEV uint32_t wide_dbl(const WideEnv<P>& e, uint32_t a) { return wide_add<
 // Montgomery product a * b * 2^(-32 N) mod p, row by row (CIOS; fp.tcc:177-263 computes the
 // same value).  After step i lane j holds column j of (T + a*b_i + m*p) / 2^32 in t and the
 // overflow of that column, still to be added to column j+1, in k.
+template <class P, int I>
+AMDMSM_DEV void wide_mul_steps(const WideEnv<P>& e, uint32_t a, uint32_t b, uint32_t& t, uint32_t& k) {
+    if constexpr (I < P::N) {
+        const uint32_t bi = row_bcast<P, I>(b);
+        const unsigned long long A = (unsigned long long)a * bi + t;
+        const uint32_t m = row_bcast<P, 0>((uint32_t)A * P::INV);
+        const unsigned long long B = (unsigned long long)m * e.pj + (uint32_t)A;
+        const unsigned long long s = (A >> 32) + (B >> 32) + k + row_down1<P>(e, (uint32_t)B);
+        t = (uint32_t)s;
+        k = (uint32_t)(s >> 32);
+        wide_mul_steps<P, I + 1>(e, a, b, t, k);
+    }
+}
+
 template <class P>
 AMDMSM_DEV uint32_t wide_mul(const WideEnv<P>& e, uint32_t a, uint32_t b) {
     uint32_t t = 0, k = 0;
-    auto step = [&](uint32_t bi) {
-        const unsigned long long A = (unsigned long long)a * bi + t;
-        const uint32_t m = row_bcast<0>((uint32_t)A * P::INV);
-        const unsigned long long B = (unsigned long long)m * e.pj + (uint32_t)A;
-        const unsigned long long s = (A >> 32) + (B >> 32) + k + row_down1((uint32_t)B);
-        t = (uint32_t)s;
-        k = (uint32_t)(s >> 32);
-    };
-    // b_i for a compile-time i
-    step(row_bcast<0>(b));
-    if (P::N > 1) step(row_bcast<1>(b));
-    if (P::N > 2) step(row_bcast<2>(b));
-    if (P::N > 3) step(row_bcast<3>(b));
-    if (P::N > 4) step(row_bcast<4>(b));
-    if (P::N > 5) step(row_bcast<5>(b));
-    if (P::N > 6) step(row_bcast<6>(b));
-    if (P::N > 7) step(row_bcast<7>(b));
-    if (P::N > 8) step(row_bcast<8>(b));
-    if (P::N > 9) step(row_bcast<9>(b));
-    if (P::N > 10) step(row_bcast<10>(b));
-    if (P::N > 11) step(row_bcast<11>(b));
-    if (P::N > 12) step(row_bcast<12>(b));
-    if (P::N > 13) step(row_bcast<13>(b));
-    if (P::N > 14) step(row_bcast<14>(b));
+    wide_mul_steps<P, 0>(e, a, b, t, k);
     // fold the pending overflows into their columns, then one conditional subtraction
-    const uint32_t kk = row_up1(k);
+    const uint32_t kk = row_up1<P>(e, k);
     uint32_t s = t + kk;
     const unsigned long long cin = carry_in_mask(s < t, s == 0xffffffffu);
     s += __builtin_amdgcn_inverse_ballot_w64(cin) ? 1u : 0u;
@@ -142,33 +152,40 @@ AMDMSM_DEV uint32_t wide_from_packed(const WideEnv<P>& e, const Fp<P, I>& x) {
     for (int i = 0; i < P::N; ++i) w = (e.j == (uint32_t)i) ? x.v[i] : w;
     return w;
 }
-template <class P, bool I>
-AMDMSM_DEV void wide_to_packed(Fp<P, I>& x, uint32_t w) {
-    x.v[0] = row_bcast<0>(w);
-    if (P::N > 1) x.v[1 % P::N] = row_bcast<1>(w);
-    if (P::N > 2) x.v[2 % P::N] = row_bcast<2>(w);
-    if (P::N > 3) x.v[3 % P::N] = row_bcast<3>(w);
-    if (P::N > 4) x.v[4 % P::N] = row_bcast<4>(w);
-    if (P::N > 5) x.v[5 % P::N] = row_bcast<5>(w);
-    if (P::N > 6) x.v[6 % P::N] = row_bcast<6>(w);
-    if (P::N > 7) x.v[7 % P::N] = row_bcast<7>(w);
-    if (P::N > 8) x.v[8 % P::N] = row_bcast<8>(w);
-    if (P::N > 9) x.v[9 % P::N] = row_bcast<9>(w);
-    if (P::N > 10) x.v[10 % P::N] = row_bcast<10>(w);
-    if (P::N > 11) x.v[11 % P::N] = row_bcast<11>(w);
-    if (P::N > 12) x.v[12 % P::N] = row_bcast<12>(w);
-    if (P::N > 13) x.v[13 % P::N] = row_bcast<13>(w);
-    if (P::N > 14) x.v[14 % P::N] = row_bcast<14>(w);
+template <class P, bool I, int K>
+AMDMSM_DEV void wide_unpack(Fp<P, I>& x, uint32_t w) {
+    if constexpr (K < P::N) {
+        x.v[K] = row_bcast<P, K>(w);
+        wide_unpack<P, I, K + 1>(x, w);
+    }
 }
+template <class P, bool I>
+AMDMSM_DEV void wide_to_packed(Fp<P, I>& x, uint32_t w) { wide_unpack<P, I, 0>(x, w); }
 
-// the element of row r, copied to every row
+// the element of row r, copied to every row (16-lane rows / any row width)
+template <class P>
+AMDMSM_DEV uint32_t row_copy(const WideEnv<P>& e, uint32_t w, int r) {
+    return (uint32_t)__shfl((int)w, r * WideEnv<P>::ROW + (int)e.j, 64);
+}
 AMDMSM_DEV uint32_t from_row(uint32_t w, int r) { return (uint32_t)__shfl((int)w, r * 16 + (int)(threadIdx.x & 15u), 64); }
+
+// prime field as a quad field for the one-product-at-a-time formulas (jac_dbl_seq / jac_add_seq):
+// used where a wave has only two rows
+template <class P>
+struct WideFq {
+    static AMDMSM_DEV uint32_t mul(const WideEnv<P>& e, uint32_t a, uint32_t b) { return wide_mul<P>(e, a, b); }
+    static AMDMSM_DEV uint32_t sqr(const WideEnv<P>& e, uint32_t a) { return wide_mul<P>(e, a, a); }
+    static AMDMSM_DEV uint32_t add(const WideEnv<P>& e, uint32_t a, uint32_t b) { return wide_add<P>(e, a, b); }
+    static AMDMSM_DEV uint32_t sub(const WideEnv<P>& e, uint32_t a, uint32_t b) { return wide_sub<P>(e, a, b); }
+    static AMDMSM_DEV uint32_t dbl(const WideEnv<P>& e, uint32_t a) { return wide_add<P>(e, a, a); }
+};
 
 // Jacobian doubling, a = 0 (dbl-2009-l, the formulas of alt_bn128_g1.cpp:293-335), on a point
 // whose coordinates are quads replicated in every row; the independent products of a stage sit
 // in different rows.  Same value as jac_dbl (ec.cuh).
 template <class P>
 AMDMSM_DEV void jac_dbl_wide(const WideEnv<P>& e, uint32_t& X, uint32_t& Y, uint32_t& Z) {
+    static_assert(WideEnv<P>::ROW == 16, "four rows");
     const uint32_t row = (threadIdx.x & 63u) >> 4;
     // stage 1:  row 0: XX = X^2   row 1: B = Y^2   row 2: YZ = Y*Z
     uint32_t u = row == 0 ? X : Y;

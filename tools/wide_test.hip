@@ -18,7 +18,8 @@ template <class P>
 __global__ void __launch_bounds__(64) k_test(const uint32_t* in, uint32_t* out_wide, uint32_t* out_ref, int tests) {
     constexpr int N = P::N;
     const WideEnv<P> e = wide_env<P>();
-    const uint32_t lane = threadIdx.x & 63u, row = lane >> 4, j = lane & 15u;
+    constexpr int ROW = WideEnv<P>::ROW, ROWS = 64 / ROW;
+    const uint32_t lane = threadIdx.x & 63u, row = lane / ROW, j = lane % ROW;
     for (int t = 0; t < tests; ++t) {
         const uint32_t* base = in + ((size_t)t * 4 + row) * 3 * N;
         const uint32_t a = j < N ? base[j] : 0u, b = j < N ? base[N + j] : 0u, c = j < N ? base[2 * N + j] : 0u;
@@ -28,16 +29,17 @@ __global__ void __launch_bounds__(64) k_test(const uint32_t* in, uint32_t* out_w
         res[2] = wide_sub<P>(e, a, b);
         res[3] = wide_dbl<P>(e, a);
         // doubling of (a, b, c) of row 0, replicated
-        uint32_t X = from_row(a, 0), Y = from_row(b, 0), Z = from_row(c, 0);
-        jac_dbl_wide<P>(e, X, Y, Z);
+        uint32_t X = row_copy<P>(e, a, 0), Y = row_copy<P>(e, b, 0), Z = row_copy<P>(e, c, 0);
+        if constexpr (ROW == 16) jac_dbl_wide<P>(e, X, Y, Z);
+        else jac_dbl_seq<WideFq<P>, P>(e, X, Y, Z);
         res[4] = X;
         res[5] = Y;
         res[6] = Z;
         // (row 0's a, b, c) + (row 1's a, b, c); every 16th test adds a point to itself, every
         // 16th + 1 to its negative, every 16th + 2 to infinity
         {
-            uint32_t X1 = from_row(a, 0), Y1 = from_row(b, 0), Z1 = from_row(c, 0);
-            uint32_t X2 = from_row(a, 1), Y2 = from_row(b, 1), Z2 = from_row(c, 1);
+            uint32_t X1 = row_copy<P>(e, a, 0), Y1 = row_copy<P>(e, b, 0), Z1 = row_copy<P>(e, c, 0);
+            uint32_t X2 = row_copy<P>(e, a, 1), Y2 = row_copy<P>(e, b, 1), Z2 = row_copy<P>(e, c, 1);
             if (t % 16 == 0 || t % 16 == 1) {
                 X2 = X1;
                 Y2 = Y1;
@@ -46,15 +48,16 @@ __global__ void __launch_bounds__(64) k_test(const uint32_t* in, uint32_t* out_w
             if (t % 16 == 1) Y2 = wide_sub<P>(e, 0u, Y2);
             if (t % 16 == 2) Z2 = 0;
             if (t % 16 == 3) Z1 = 0;
-            jac_add_wide<P>(e, X1, Y1, Z1, X2, Y2, Z2);
+            if constexpr (ROW == 16) jac_add_wide<P>(e, X1, Y1, Z1, X2, Y2, Z2);
+            else jac_add_seq<WideFq<P>, P>(e, X1, Y1, Z1, X2, Y2, Z2);
             res[7] = X1;
             res[8] = Y1;
             res[9] = Z1;
         }
         for (int q = 0; q < 10; ++q)
             if (j < N) out_wide[(((size_t)t * 4 + row) * 10 + q) * N + j] = res[q];
-        // reference: lane r (< 4) does row r with the per-lane code
-        if (lane < 4) {
+        // reference: lane r (< rows) does row r with the per-lane code
+        if (lane < (uint32_t)ROWS) {
             const uint32_t* bs = in + ((size_t)t * 4 + lane) * 3 * N;
             Fp<P, false> fa, fb, r;
             for (int i = 0; i < N; ++i) {
@@ -147,7 +150,7 @@ int run(const char* name) {
     const char* ops[10] = {"mul", "add", "sub", "dbl", "jdbl.X", "jdbl.Y", "jdbl.Z", "jadd.X", "jadd.Y", "jadd.Z"};
     int bad[10] = {};
     for (int t = 0; t < tests; ++t)
-        for (int row = 0; row < 4; ++row)
+        for (int row = 0; row < 64 / WideEnv<P>::ROW; ++row)
             for (int q = 0; q < 10; ++q) {
                 const size_t o = (((size_t)t * 4 + row) * 10 + q) * N;
                 bool same = true;
@@ -311,7 +314,7 @@ int run2(const char* name) {
 }
 
 int main() {
-    int bad = run<alt_bn128_fq>("alt_bn128_fq") + run<bls12_377_fq>("bls12_377_fq");
+    int bad = run<alt_bn128_fq>("alt_bn128_fq") + run<bls12_377_fq>("bls12_377_fq") + run<bw6_761_fq>("bw6_761_fq");
     bad += run2<alt_bn128_fq, -1>("alt_bn128_fq2") + run2<bls12_377_fq, -5>("bls12_377_fq2");
     printf(bad ? "WIDE TEST FAILED\n" : "WIDE TEST PASSED\n");
     return bad ? 1 : 0;
