@@ -51,6 +51,7 @@ struct group_vtable {
     int curve, group;
     int fr_words;      // 32-bit words per scalar
     int el_words;      // 32-bit words per coordinate (Fq or Fq2)
+    int fq_words;      // 32-bit limbs of the base prime field
     int fr_bits;       // bit length of the scalar-field modulus
     int projective;    // libff stores this group in homogeneous projective coordinates
     const uint32_t* fr_one_mont;   // Fr::one() in Montgomery form (R mod r), fr_words words

@@ -1751,7 +1751,7 @@ void l_madd_bench(hipStream_t st, const uint32_t* pts, uint32_t* out, size_t nth
 }
 
 const group_vtable g_vt = {
-    GP::CURVE, GP::GROUP, FRW, EW, FR::BITS, GP::LIBFF_PROJECTIVE ? 1 : 0, FR::R,
+    GP::CURVE, GP::GROUP, FRW, EW, FQ::N, FR::BITS, GP::LIBFF_PROJECTIVE ? 1 : 0, FR::R,
     l_import_bases, l_precompute_table, l_count, l_scatter, l_sort, l_accumulate, l_accumulate_fixup, l_reduce_segments, l_sum_butterfly, l_horner, l_sum_points,
     l_gen_bases_seq, l_export_affine, l_ffi_decode_points, l_ffi_decode_scalars, l_ffi_encode_point, l_disk_decode, l_fixed_base_exp, l_field_op, l_group_op, l_digits, l_mul_bench, l_madd_bench,
 };
