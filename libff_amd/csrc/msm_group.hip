@@ -335,11 +335,12 @@ constexpr int SORT_MAX_FB = 11;     // c <= 22
 
 AMDMSM_DEV uint32_t digit_payload(size_t i, int32_t d) { return (uint32_t)i | (d < 0 ? 0x80000000u : 0u); }
 
-// exclusive scan of cnt[0..len) (LDS) into out[0..len) by one workgroup of SORT_TPB threads;
-// len <= 8 * SORT_TPB.  tmp: SORT_TPB/64 + 1 words of LDS.  Returns the total in every thread.
+// exclusive scan of cnt[0..len) (LDS) into out[0..len) by one workgroup of NT threads;
+// len <= 8 * NT.  tmp: NT/64 + 1 words of LDS.  Returns the total in every thread.
+template <int NT = SORT_TPB>
 AMDMSM_DEV uint32_t block_exclusive_scan(const uint32_t* cnt, uint32_t* out, uint32_t len, uint32_t* tmp) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t per = (len + SORT_TPB - 1) / SORT_TPB;   // <= 8
+    const uint32_t per = (len + NT - 1) / NT;   // <= 8
     const uint32_t i0 = tid * per;
     uint32_t v[8];
     uint32_t tsum = 0;
@@ -359,7 +360,7 @@ AMDMSM_DEV uint32_t block_exclusive_scan(const uint32_t* cnt, uint32_t* out, uin
     __syncthreads();
     uint32_t wave_off = 0, total = 0;
 #pragma unroll
-    for (uint32_t k = 0; k < SORT_TPB / 64; ++k) {
+    for (uint32_t k = 0; k < NT / 64; ++k) {
         const uint32_t ws = tmp[k];
         if (k < wave) wave_off += ws;
         total += ws;
@@ -470,7 +471,10 @@ __global__ void __launch_bounds__(SORT_TPB) k_sort_coarse(const int32_t* __restr
     }
 }
 
-__global__ void __launch_bounds__(SORT_TPB) k_sort_fine(const uint32_t* __restrict__ tmp_payload,
+// NT threads per workgroup: 1024 for bins of tens of thousands of entries, 256 when a bin holds
+// a few thousand at most (2^20-point inputs), where barriers between 16 waves would dominate
+template <int NT>
+__global__ void __launch_bounds__(NT) k_sort_fine(const uint32_t* __restrict__ tmp_payload,
                                                         const uint32_t* __restrict__ tmp_key,
                                                         const uint32_t* __restrict__ coarse, size_t stride, int c, int hb,
                                                         uint32_t chunk_cap, uint32_t big_thresh, uint32_t big_cap,
@@ -478,7 +482,7 @@ __global__ void __launch_bounds__(SORT_TPB) k_sort_fine(const uint32_t* __restri
                                                         uint32_t* __restrict__ lists) {
     // dynamic LDS: 4 arrays of nfine words, chunk_cap payload words, chunk_cap fine keys (u16)
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    __shared__ uint32_t tmp[SORT_TPB / 64 + 1];
+    __shared__ uint32_t tmp[NT / 64 + 1];
     const uint32_t nbin = 1u << hb;
     const int fb = c - 1 - hb;
     const uint32_t nfine = 1u << fb, fmask = nfine - 1u;
@@ -498,7 +502,7 @@ __global__ void __launch_bounds__(SORT_TPB) k_sort_fine(const uint32_t* __restri
     if (m > big_thresh) {
         // oversized bin (many equal or clustered scalars): leave it to the cooperative kernels
         // below; its bucket counts are gathered in ends[] first, so clear them
-        for (uint32_t j = threadIdx.x; j < nfine; j += SORT_TPB) e[j] = 0;
+        for (uint32_t j = threadIdx.x; j < nfine; j += NT) e[j] = 0;
         if (threadIdx.x == 0) {
             const uint32_t tiles = (m + SORT_TILE - 1) / SORT_TILE;
             const uint32_t slot = atomicAdd(&big[0], 1u);   // < big_cap: sum of m over such bins <= W * n
@@ -511,36 +515,36 @@ __global__ void __launch_bounds__(SORT_TPB) k_sort_fine(const uint32_t* __restri
         return;
     }
     // pass A: sizes of the fine buckets of this bin -> ends[]
-    for (uint32_t j = threadIdx.x; j < nfine; j += SORT_TPB) chist[j] = 0;
+    for (uint32_t j = threadIdx.x; j < nfine; j += NT) chist[j] = 0;
     __syncthreads();
-    for (uint32_t k = threadIdx.x; k < m; k += SORT_TPB) atomicAdd(&chist[key[k] & fmask], 1u);
+    for (uint32_t k = threadIdx.x; k < m; k += NT) atomicAdd(&chist[key[k] & fmask], 1u);
     __syncthreads();
-    block_exclusive_scan(chist, fstart, nfine, tmp);
-    for (uint32_t j = threadIdx.x; j < nfine; j += SORT_TPB) e[j] = b0 + fstart[j] + chist[j];
+    block_exclusive_scan<NT>(chist, fstart, nfine, tmp);
+    for (uint32_t j = threadIdx.x; j < nfine; j += NT) e[j] = b0 + fstart[j] + chist[j];
     __syncthreads();
     // pass B: chunk-wise counting sort; fstart[f] advances as chunks are placed
     for (uint32_t c0 = 0; c0 < m; c0 += chunk_cap) {
         const uint32_t cm = (m - c0 < chunk_cap) ? m - c0 : chunk_cap;
-        for (uint32_t j = threadIdx.x; j < nfine; j += SORT_TPB) chist[j] = 0;
+        for (uint32_t j = threadIdx.x; j < nfine; j += NT) chist[j] = 0;
         __syncthreads();
-        for (uint32_t k = threadIdx.x; k < cm; k += SORT_TPB) atomicAdd(&chist[key[c0 + k] & fmask], 1u);
+        for (uint32_t k = threadIdx.x; k < cm; k += NT) atomicAdd(&chist[key[c0 + k] & fmask], 1u);
         __syncthreads();
-        block_exclusive_scan(chist, cstart, nfine, tmp);
-        for (uint32_t j = threadIdx.x; j < nfine; j += SORT_TPB) ccur[j] = cstart[j];
+        block_exclusive_scan<NT>(chist, cstart, nfine, tmp);
+        for (uint32_t j = threadIdx.x; j < nfine; j += NT) ccur[j] = cstart[j];
         __syncthreads();
-        for (uint32_t k = threadIdx.x; k < cm; k += SORT_TPB) {
+        for (uint32_t k = threadIdx.x; k < cm; k += NT) {
             const uint32_t f = key[c0 + k] & fmask;
             const uint32_t r = atomicAdd(&ccur[f], 1u);
             st_payload[r] = pay[c0 + k];
             st_fine[r] = (unsigned short)f;
         }
         __syncthreads();
-        for (uint32_t k = threadIdx.x; k < cm; k += SORT_TPB) {
+        for (uint32_t k = threadIdx.x; k < cm; k += NT) {
             const uint32_t f = st_fine[k];
             out[fstart[f] + (k - cstart[f])] = st_payload[k];
         }
         __syncthreads();
-        for (uint32_t j = threadIdx.x; j < nfine; j += SORT_TPB) fstart[j] += chist[j];
+        for (uint32_t j = threadIdx.x; j < nfine; j += NT) fstart[j] += chist[j];
         __syncthreads();
     }
 }
@@ -1634,8 +1638,12 @@ void l_sort(hipStream_t st, const uint32_t* scalars, size_t n, int mont, int c, 
     hipLaunchKernelGGL(k_sort_coarse, dim3((unsigned)((ne + SORT_TILE - 1) / SORT_TILE), We), dim3(SORT_TPB), 0, st, digits,
                        ne, stride, c, hb, cursor, tmp_payload, tmp_key);
     const size_t fine_lds = ((size_t)4 << sg.fb) * 4 + (size_t)sg.chunk_cap * 6;
-    hipLaunchKernelGGL(k_sort_fine, dim3(nbin, We), dim3(SORT_TPB), fine_lds, st, tmp_payload, tmp_key, coarse, stride, c, hb,
-                       sg.chunk_cap, sg.big_thresh, sg.big_cap, big, ends, lists);
+    if (sg.chunk_cap <= 4096)
+        hipLaunchKernelGGL(k_sort_fine<256>, dim3(nbin, We), dim3(256), fine_lds, st, tmp_payload, tmp_key, coarse, stride,
+                           c, hb, sg.chunk_cap, sg.big_thresh, sg.big_cap, big, ends, lists);
+    else
+        hipLaunchKernelGGL(k_sort_fine<SORT_TPB>, dim3(nbin, We), dim3(SORT_TPB), fine_lds, st, tmp_payload, tmp_key, coarse,
+                           stride, c, hb, sg.chunk_cap, sg.big_thresh, sg.big_cap, big, ends, lists);
     hipLaunchKernelGGL(k_sort_big_hist, dim3(2048), dim3(SORT_TPB), 0, st, tmp_key, coarse, stride, c, hb, big, ends);
     hipLaunchKernelGGL(k_sort_big_scan, dim3(256), dim3(SORT_TPB), 0, st, coarse, c, hb, sg.big_cap, big, ends);
     const size_t big_lds = ((size_t)4 << sg.fb) * 4 + (size_t)SORT_TILE * 6;
