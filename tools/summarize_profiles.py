@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def main():
     tag, stats, fetch, write, curve, group, log2n, c = sys.argv[1:9]
     rows = list(csv.reader(open(stats)))
-    out = [rows[0]] + [r for r in rows[1:] if r[0].startswith("amdmsm")]
+    out = [rows[0]] + [r for r in rows[1:] if "amdmsm" in r[0]]
     csv.writer(open(os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv"), "w")).writerows(out)
     res = {}
     for name, f in (("FETCH_SIZE", fetch), ("WRITE_SIZE", write)):
