@@ -1,7 +1,7 @@
 """Build libff_amd/libamdmsm.so for gfx950 with hipcc (in-tree, no JIT cache).
 
 One translation unit per (curve, group) pair -- msm_group.hip compiled with
--DAMDMSM_GROUP=... -- plus the host engine; the six device TUs build in parallel.
+-DAMDMSM_GROUP=... -- plus the host engine; the eight device TUs build in parallel.
 Objects are cached under libff_amd/csrc/build/ keyed by source mtimes.
 """
 import concurrent.futures

@@ -55,7 +55,7 @@ struct amdmsm_ctx {
 
 namespace {
 
-// The six group translation units are linked weakly so a development build may carry a
+// The eight group translation units are linked weakly so a development build may carry a
 // subset (AMDMSM_GROUPS=... python -m libff_amd.build); absent groups report UNSUPPORTED.
 using vt_getter = const group_vtable *(*)();
 const group_vtable *find_vt(int curve, int group) {

@@ -1,14 +1,14 @@
 // MSM kernels for ONE (curve, group) pair on gfx950.  Compiled once per group with
 //   -DAMDMSM_GROUP=<traits struct from curve_params.h> -DAMDMSM_VT=<vtable getter>
-// so the six groups build in parallel and every modulus limb is a compile-time
+// so the eight groups build in parallel and every modulus limb is a compile-time
 // constant in the instruction stream.
 //
 // Pipeline (the device-side restatement of multi_exp_inner<BDLO12_signed>,
 // multiexp.tcc:563-632, re-shaped for a throughput machine):
-//   k_count      signed radix-2^c recoding of every scalar (field_get_signed_digit,
-//                field_utils.tcc:167-203) -> per-(window, bucket) histogram
-//   k_scan       exclusive scan of the histogram, one workgroup per window
-//   k_scatter    second recoding pass -> per-window point lists grouped by bucket
+//   k_sort_*     signed radix-2^c recoding of every scalar (field_get_signed_digits,
+//                field_utils.tcc:205-239) and a two-level LDS-staged bucket sort -> per-window
+//                point lists grouped by bucket (k_count / k_scan / k_scatter: the global-atomic
+//                fallback for c > 22)
 //   k_accumulate one lane per S consecutive entries of a window's sorted list (segmented sum
 //                by bucket, fixed work per lane): mixed additions
 //                (multi_exp_add_element_to_bucket_with_signed_digit, multiexp.tcc:45-81);
@@ -17,7 +17,8 @@
 //                sum_b (b+1) * B_b (multiexp_accumulate_buckets, multiexp.tcc:90-125)
 //                as L-bucket running sums + a small scalar multiple per segment, folded
 //                64:1 per wave with XOR butterflies
-//   k_horner     high-to-low window combination with c doublings (multiexp.tcc:612-629)
+//   k_horner     high-to-low window combination with c doublings (multiexp.tcc:612-629) on
+//                lane-split field elements (wide.cuh)
 //
 // All windows are processed at once: the libff loop "for round ... signed_digits_round"
 // becomes the W dimension of every grid.
