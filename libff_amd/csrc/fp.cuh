@@ -65,15 +65,28 @@ AMDMSM_DEV bool fp_eq(const Fp<P, I>& a, const Fp<P, I>& b) {
     return acc == 0;
 }
 
+// Limb-wise add / subtract with carry: __builtin_addc / __builtin_subc lower to v_add_co_u32 /
+// v_addc_co_u32 chains on gfx950 (one issue per limb; expressing the same through 64-bit
+// integers costs a half-rate v_lshl_add_u64 plus shift and move per limb).
+AMDMSM_DEV uint32_t addc32(uint32_t a, uint32_t b, uint32_t& carry) {
+    unsigned co;
+    const uint32_t r = __builtin_addc(a, b, carry, &co);
+    carry = co;
+    return r;
+}
+AMDMSM_DEV uint32_t subb32(uint32_t a, uint32_t b, uint32_t& borrow) {
+    unsigned bo;
+    const uint32_t r = __builtin_subc(a, b, borrow, &bo);
+    borrow = bo;
+    return r;
+}
+
 // a < p as plain integers
 template <class P, bool I>
 AMDMSM_DEV bool fp_lt_modulus(const Fp<P, I>& a) {
     uint32_t borrow = 0;
 #pragma unroll
-    for (int i = 0; i < P::N; ++i) {
-        const uint64_t s = (uint64_t)a.v[i] - P::P[i] - borrow;
-        borrow = (uint32_t)(s >> 63);
-    }
+    for (int i = 0; i < P::N; ++i) (void)subb32(a.v[i], P::P[i], borrow);
     return borrow != 0;
 }
 
@@ -83,11 +96,7 @@ AMDMSM_DEV void fp_reduce_once(uint32_t (&t)[P::N]) {
     uint32_t d[P::N];
     uint32_t borrow = 0;
 #pragma unroll
-    for (int i = 0; i < P::N; ++i) {
-        const uint64_t s = (uint64_t)t[i] - P::P[i] - borrow;
-        d[i] = (uint32_t)s;
-        borrow = (uint32_t)(s >> 63);
-    }
+    for (int i = 0; i < P::N; ++i) d[i] = subb32(t[i], P::P[i], borrow);
 #pragma unroll
     for (int i = 0; i < P::N; ++i) t[i] = borrow ? t[i] : d[i];
 }
@@ -97,11 +106,7 @@ AMDMSM_DEV void fp_add(Fp<P, I>& r, const Fp<P, I>& a, const Fp<P, I>& b) {
     uint32_t t[P::N];
     uint32_t carry = 0;
 #pragma unroll
-    for (int i = 0; i < P::N; ++i) {
-        const uint64_t s = (uint64_t)a.v[i] + b.v[i] + carry;
-        t[i] = (uint32_t)s;
-        carry = (uint32_t)(s >> 32);
-    }
+    for (int i = 0; i < P::N; ++i) t[i] = addc32(a.v[i], b.v[i], carry);
     // p < 2^(32N-1): a + b < 2p < 2^(32N), so the carry out is always 0
     fp_reduce_once<P>(t);
 #pragma unroll
@@ -113,20 +118,12 @@ AMDMSM_DEV void fp_sub(Fp<P, I>& r, const Fp<P, I>& a, const Fp<P, I>& b) {
     uint32_t t[P::N];
     uint32_t borrow = 0;
 #pragma unroll
-    for (int i = 0; i < P::N; ++i) {
-        const uint64_t s = (uint64_t)a.v[i] - b.v[i] - borrow;
-        t[i] = (uint32_t)s;
-        borrow = (uint32_t)(s >> 63);
-    }
+    for (int i = 0; i < P::N; ++i) t[i] = subb32(a.v[i], b.v[i], borrow);
     // add p back when the subtraction borrowed
     const uint32_t mask = 0u - borrow;
     uint32_t carry = 0;
 #pragma unroll
-    for (int i = 0; i < P::N; ++i) {
-        const uint64_t s = (uint64_t)t[i] + (P::P[i] & mask) + carry;
-        r.v[i] = (uint32_t)s;
-        carry = (uint32_t)(s >> 32);
-    }
+    for (int i = 0; i < P::N; ++i) r.v[i] = addc32(t[i], P::P[i] & mask, carry);
 }
 
 template <class P, bool I>
@@ -148,11 +145,7 @@ AMDMSM_DEV void fp_neg(Fp<P, I>& r, const Fp<P, I>& a) {
     const uint32_t mask = fp_is_zero(a) ? 0u : 0xffffffffu;   // -0 = 0 (fp.tcc:623-628)
     uint32_t borrow = 0;
 #pragma unroll
-    for (int i = 0; i < P::N; ++i) {
-        const uint64_t s = (uint64_t)P::P[i] - a.v[i] - borrow;
-        r.v[i] = (uint32_t)s & mask;
-        borrow = (uint32_t)(s >> 63);
-    }
+    for (int i = 0; i < P::N; ++i) r.v[i] = subb32(P::P[i], a.v[i], borrow) & mask;
 }
 
 // conditional negate: r = neg ? -a : a
