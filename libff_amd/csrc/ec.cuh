@@ -298,6 +298,55 @@ AMDMSM_DEV void xyzz_madd(Xyzz<E>& acc, const Aff<E>& p) {
     el_sub(acc.y, q, t);          // Y3
 }
 
+// The same on almost-reduced coordinates (fp.cuh: every coordinate of acc in [0, 2p), p
+// canonical): no conditional subtraction after the ten products.  The rare special cases go
+// through the canonical code.  xyzz_canon before acc is stored or handed to anything else.
+template <class E>
+AMDMSM_DEV void xyzz_canon(Xyzz<E>& a) {
+    el_canon(a.x);
+    el_canon(a.y);
+    el_canon(a.zz);
+    el_canon(a.zzz);
+}
+template <class E>
+AMDMSM_DEV void xyzz_madd_lz(Xyzz<E>& acc, const Aff<E>& p) {
+    if (aff_is_inf(p)) return;
+    if (el_is_zero_lz(acc.zz)) {   // infinity
+        acc.x = p.x;
+        acc.y = p.y;
+        el_one(acc.zz);
+        el_one(acc.zzz);
+        return;
+    }
+    E pp, r, ppp, q, t;
+    el_mul_lz(pp, p.x, acc.zz);      // U2
+    el_mul_lz(r, p.y, acc.zzz);      // S2
+    el_sub_lz(pp, pp, acc.x);        // P = U2 - X1
+    el_sub_lz(r, r, acc.y);          // R = S2 - Y1
+    if (el_is_zero_lz(pp)) {
+        if (el_is_zero_lz(r)) {
+            xyzz_canon(acc);
+            xyzz_dbl_affine(acc, p);   // same point: 2*P
+        } else {
+            xyzz_set_inf(acc);         // opposite points
+        }
+        return;
+    }
+    el_sqr_lz(ppp, pp);              // PP (kept in ppp for a moment)
+    el_mul_lz(q, acc.x, ppp);        // Q = X1*PP
+    el_mul_lz(acc.zz, acc.zz, ppp);  // ZZ3 = ZZ1*PP
+    el_mul_lz(ppp, pp, ppp);         // PPP = P*PP
+    el_mul_lz(acc.zzz, acc.zzz, ppp);   // ZZZ3 = ZZZ1*PPP
+    el_sqr_lz(t, r);
+    el_sub_lz(t, t, ppp);
+    el_sub_lz(t, t, q);
+    el_sub_lz(acc.x, t, q);          // X3 = R^2 - PPP - 2Q
+    el_sub_lz(q, q, acc.x);
+    el_mul_lz(q, r, q);              // R*(Q - X3)
+    el_mul_lz(t, acc.y, ppp);        // Y1*PPP
+    el_sub_lz(acc.y, q, t);          // Y3
+}
+
 // r = a + b, add-2008-s (r may alias a)
 template <class E>
 AMDMSM_DEV void xyzz_add(Xyzz<E>& r, const Xyzz<E>& a, const Xyzz<E>& b) {

@@ -216,14 +216,14 @@ AMDMSM_DEV void fp_mul_column(uint64_t& lo, uint32_t& hi, uint32_t* m, uint32_t*
     if constexpr (K + 1 < 2 * N) fp_mul_column<P, K + 1>(lo, hi, m, t, a, b);
 }
 
-template <class P>
+template <class P, bool REDUCE = true>
 AMDMSM_DEV void fp_mul_core(uint32_t (&r)[P::N], const uint32_t (&a)[P::N], const uint32_t (&b)[P::N]) {
     constexpr int N = P::N;
     uint32_t m[N], t[N];
     uint64_t lo = 0;
     uint32_t hi = 0;
     fp_mul_column<P, 0>(lo, hi, m, t, a, b);
-    fp_reduce_once<P>(t);
+    if constexpr (REDUCE) fp_reduce_once<P>(t);
 #pragma unroll
     for (int i = 0; i < N; ++i) r[i] = t[i];
 }
@@ -260,6 +260,67 @@ AMDMSM_DEV void fp_mul(Fp<P, I>& r, const Fp<P, I>& a, const Fp<P, I>& b) {
 template <class P, bool I>
 AMDMSM_DEV void fp_sqr(Fp<P, I>& r, const Fp<P, I>& a) {
     fp_mul(r, a, a);
+}
+
+// ---- almost-reduced arithmetic: values in [0, 2p) ----------------------------------------
+// With 4p <= 2^(32N) (true for every supported modulus) a Montgomery product of operands below
+// 2p is itself below 2p, so inside a chain of field operations the conditional subtraction
+// after every product can be dropped; additions / subtractions keep their results below 2p at
+// the usual cost.  Used by the bucket-accumulation loop (xyzz_madd_lz), which canonicalises
+// (fp_canon) only what it stores.  "Zero" is 0 or p in this representation.
+template <class P>
+AMDMSM_DEV constexpr uint32_t fp_2p_limb(int k) {
+    return (P::P[k] << 1) | (k ? (P::P[k - 1] >> 31) : 0u);
+}
+template <class P, bool I>
+AMDMSM_DEV void fp_mul_lz(Fp<P, I>& r, const Fp<P, I>& a, const Fp<P, I>& b) {
+    static_assert(P::P[P::N - 1] < 0x40000000u, "needs 4p <= 2^(32N)");
+    if constexpr (I) fp_mul_core<P, false>(r.v, a.v, b.v);
+    else fp_mul(r, a, b);
+}
+template <class P, bool I>
+AMDMSM_DEV void fp_add_lz(Fp<P, I>& r, const Fp<P, I>& a, const Fp<P, I>& b) {
+    uint32_t t[P::N], d[P::N];
+    uint32_t carry = 0, borrow = 0;
+#pragma unroll
+    for (int i = 0; i < P::N; ++i) t[i] = addc32(a.v[i], b.v[i], carry);   // < 4p <= 2^(32N)
+#pragma unroll
+    for (int i = 0; i < P::N; ++i) d[i] = subb32(t[i], fp_2p_limb<P>(i), borrow);
+#pragma unroll
+    for (int i = 0; i < P::N; ++i) r.v[i] = borrow ? t[i] : d[i];
+}
+template <class P, bool I>
+AMDMSM_DEV void fp_sub_lz(Fp<P, I>& r, const Fp<P, I>& a, const Fp<P, I>& b) {
+    uint32_t t[P::N];
+    uint32_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < P::N; ++i) t[i] = subb32(a.v[i], b.v[i], borrow);
+    const uint32_t mask = 0u - borrow;   // negative: add 2p
+    uint32_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < P::N; ++i) r.v[i] = addc32(t[i], fp_2p_limb<P>(i) & mask, carry);
+}
+template <class P, bool I>
+AMDMSM_DEV bool fp_is_zero_lz(const Fp<P, I>& a) {
+    uint32_t z = 0, e = 0;
+#pragma unroll
+    for (int i = 0; i < P::N; ++i) {
+        z |= a.v[i];
+        e |= a.v[i] ^ P::P[i];
+    }
+    return z == 0 || e == 0;
+}
+template <class P, bool I>
+AMDMSM_DEV void fp_neg_lz(Fp<P, I>& r, const Fp<P, I>& a) {
+    const uint32_t mask = fp_is_zero_lz(a) ? 0u : 0xffffffffu;
+    uint32_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < P::N; ++i) r.v[i] = subb32(fp_2p_limb<P>(i), a.v[i], borrow) & mask;
+}
+// [0, 2p) -> [0, p)
+template <class P, bool I>
+AMDMSM_DEV void fp_canon(Fp<P, I>& a) {
+    fp_reduce_once<P>(a.v);
 }
 
 // Montgomery reduction of a single element: a * R^-1 mod p  (as_bigint, fp.tcc:270-281)

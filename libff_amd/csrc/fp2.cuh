@@ -175,4 +175,63 @@ template <class P, int NR, bool I> AMDMSM_DEV void el_store(uint32_t* p, const F
     fp_store(p + P::N, a.c1);
 }
 
+// ---- almost-reduced ([0, 2p) per component) overload set, see fp.cuh ------------------------
+template <class P, bool I> AMDMSM_DEV void el_mul_lz(Fp<P, I>& r, const Fp<P, I>& a, const Fp<P, I>& b) { fp_mul_lz(r, a, b); }
+template <class P, bool I> AMDMSM_DEV void el_sqr_lz(Fp<P, I>& r, const Fp<P, I>& a) { fp_mul_lz(r, a, a); }
+template <class P, bool I> AMDMSM_DEV void el_sub_lz(Fp<P, I>& r, const Fp<P, I>& a, const Fp<P, I>& b) { fp_sub_lz(r, a, b); }
+template <class P, bool I> AMDMSM_DEV bool el_is_zero_lz(const Fp<P, I>& a) { return fp_is_zero_lz(a); }
+template <class P, bool I> AMDMSM_DEV void el_canon(Fp<P, I>& a) { fp_canon(a); }
+
+template <class P, int NR, bool I>
+AMDMSM_DEV void fp_mul_nr_lz(Fp<P, I>& r, const Fp<P, I>& x) {
+    if (NR == -1) {
+        fp_neg_lz(r, x);
+    } else {
+        Fp<P, I> t;
+        fp_add_lz(t, x, x);
+        fp_add_lz(t, t, t);
+        fp_add_lz(t, t, x);
+        fp_neg_lz(r, t);
+    }
+}
+template <class P, int NR, bool I>
+AMDMSM_DEV void el_mul_lz(Fp2<P, NR, I>& r, const Fp2<P, NR, I>& x, const Fp2<P, NR, I>& y) {
+    Fp<P, I> aA, bB, s1, s2, t;
+    fp_mul_lz(aA, x.c0, y.c0);
+    fp_mul_lz(bB, x.c1, y.c1);
+    fp_add_lz(s1, x.c0, x.c1);
+    fp_add_lz(s2, y.c0, y.c1);
+    fp_mul_lz(s1, s1, s2);
+    fp_sub_lz(s1, s1, aA);
+    fp_sub_lz(s1, s1, bB);
+    fp_mul_nr_lz<P, NR, I>(t, bB);
+    fp_add_lz(r.c0, aA, t);
+    r.c1 = s1;
+}
+template <class P, int NR, bool I>
+AMDMSM_DEV void el_sqr_lz(Fp2<P, NR, I>& r, const Fp2<P, NR, I>& x) {
+    Fp<P, I> ab, s1, s2, t;
+    fp_mul_lz(ab, x.c0, x.c1);
+    fp_add_lz(s1, x.c0, x.c1);
+    fp_mul_nr_lz<P, NR, I>(t, x.c1);
+    fp_add_lz(s2, x.c0, t);
+    fp_mul_lz(s1, s1, s2);
+    fp_sub_lz(s1, s1, ab);
+    fp_mul_nr_lz<P, NR, I>(t, ab);
+    fp_sub_lz(r.c0, s1, t);
+    fp_add_lz(r.c1, ab, ab);
+}
+template <class P, int NR, bool I>
+AMDMSM_DEV void el_sub_lz(Fp2<P, NR, I>& r, const Fp2<P, NR, I>& a, const Fp2<P, NR, I>& b) {
+    fp_sub_lz(r.c0, a.c0, b.c0);
+    fp_sub_lz(r.c1, a.c1, b.c1);
+}
+template <class P, int NR, bool I>
+AMDMSM_DEV bool el_is_zero_lz(const Fp2<P, NR, I>& a) { return fp_is_zero_lz(a.c0) && fp_is_zero_lz(a.c1); }
+template <class P, int NR, bool I>
+AMDMSM_DEV void el_canon(Fp2<P, NR, I>& a) {
+    fp_canon(a.c0);
+    fp_canon(a.c1);
+}
+
 }  // namespace amdmsm

@@ -49,6 +49,11 @@ using FR = typename GP::fr;
 #ifndef AMDMSM_BENCH_BOTH
 #define AMDMSM_BENCH_BOTH 0
 #endif
+// k_accumulate on almost-reduced coordinates (no conditional subtraction after a product,
+// fp.cuh): 2-6 % faster except where it costs registers (alt_bn128 G2: 29 % slower, so off there)
+#ifndef AMDMSM_ACC_LAZY
+#define AMDMSM_ACC_LAZY 1
+#endif
 template <int DEG, bool I> struct coord_sel;
 template <bool I> struct coord_sel<1, I> { using type = Fp<FQ, I>; };
 template <bool I> struct coord_sel<2, I> { using type = Fp2<FQ, GP::NR_SMALL == 0 ? -1 : GP::NR_SMALL, I>; };
@@ -733,6 +738,7 @@ __global__ void __launch_bounds__(TPB) k_accumulate(const uint32_t* __restrict__
     for (uint32_t k = lo; k < hi; ++k) {
         if (k == bend) {
             // bucket b ends here: it is complete unless its head lies in an earlier lane
+            xyzz_canon(acc);
             store_xyzz(from_prev ? part_first + g * ZZW : bk + (size_t)b * ZZW, acc);
             from_prev = false;
             xyzz_set_inf(acc);
@@ -745,8 +751,13 @@ __global__ void __launch_bounds__(TPB) k_accumulate(const uint32_t* __restrict__
         Aff<EH> p;
         load_aff(p, bases + (size_t)(ent & 0x7fffffffu) * AFFW);
         el_cneg(p.y, p.y, (ent >> 31) != 0);   // -(x, y) = (x, -y); (0,0) stays infinity
+#if AMDMSM_ACC_LAZY
+        xyzz_madd_lz(acc, p);   // coordinates of acc stay in [0, 2p) between stores
+#else
         xyzz_madd(acc, p);
+#endif
     }
+    xyzz_canon(acc);
     if (bend == hi) {   // the last bucket ends exactly with the lane
         store_xyzz(from_prev ? part_first + g * ZZW : bk + (size_t)b * ZZW, acc);
         cont_bucket[g] = NO_BUCKET;
