@@ -38,6 +38,14 @@ CURVES = {"alt_bn128": 0, "bls12_377": 1, "bw6_761": 2, "bls12_381": 3}
 # one scalar + one affine base per scalar-mul
 ALGO_BYTES = {(0, 1): 96, (1, 1): 128, (1, 2): 224, (2, 1): 240, (0, 2): 160, (2, 2): 240, (3, 1): 128, (3, 2): 224}
 HBM_PEAK_GBS = 8000.0
+# What bounds k_accumulate is the issue rate of its multiply-accumulate pairs (v_mad_u64_u32 +
+# v_addc_co_u32, both half rate): 33.15 T lane-instructions/s measured with 4 waves per SIMD
+# (profiles/r01_ubench_instruction_rates.txt).  One Fq product = 2 N^2 pairs on N 32-bit limbs; one
+# mixed addition = 10 coordinate products (8M + 2S), a coordinate product in Fq2 = 3 (M) or 2 (S)
+# Fq products.
+MAC_PAIR_PEAK = 33.15e12
+FQ_LIMBS = {0: 8, 1: 12, 2: 24, 3: 12}
+FQ_PRODUCTS_PER_MADD = {1: 10, 2: 28}
 FR_MODULUS = {
     0: 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001,
     1: 0x12AB655E9A2CA55660B44D1E5C37B00159AA76FED00000010A11800000000001,
@@ -342,6 +350,14 @@ def main():
         algo_bytes = ALGO_BYTES[(curve, group)] * n
         achieved = algo_bytes / (acc * 1e-3) / 1e9
         mean_phase = {k: float(np.mean([p[k] for p in phases])) for k in phases[0]}
+        fq_products = FQ_PRODUCTS_PER_MADD[group if not (curve == 2) else 1]
+        lane_instr = float(n) * plan["num_windows"] * fq_products * 4 * FQ_LIMBS[curve] ** 2
+        mac_rate = lane_instr / (acc * 1e-3)
+        mac_issue = {"achieved": mac_rate / 1e12, "peak": MAC_PAIR_PEAK / 1e12, "unit": "T lane-instr/s",
+                     "frac": mac_rate / MAC_PAIR_PEAK,
+                     "what": "v_mad_u64_u32 + v_addc_co_u32 issues of the Montgomery products in k_accumulate "
+                             "(upper bound: every list entry counted as a full mixed addition) against the pair's "
+                             "measured issue rate at 4 waves/SIMD"}
         out = {
             "metric": "G1 MSM throughput (scalar-muls/sec)" if group == 1 else "G2 MSM throughput (scalar-muls/sec)",
             "value": value,
@@ -376,6 +392,7 @@ def main():
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "kernel_ms": acc,
                 "note": "integer-ALU bound path (no MFMA); HBM fraction is small by construction",
+                "mac_issue": mac_issue,
             },
             "phases_ms": mean_phase,
         }
