@@ -160,7 +160,7 @@ def main():
     ap.add_argument("--pipeline", type=int, default=int(os.environ.get("AMDMSM_BENCH_PIPELINE", "1")),
                     help="MSMs in flight in the timed region (1 = strictly one after the other, which is "
                          "what `value` and the roofline kernel timings are quoted on)")
-    ap.add_argument("--also-pipelined", type=int, default=2,
+    ap.add_argument("--also-pipelined", type=int, default=3,
                     help="after the timed region, also measure the same workload with this many MSMs in flight "
                          "(reported under 'pipelined'); 0 disables")
     ap.add_argument("--precomputed-c", type=int, default=16,
