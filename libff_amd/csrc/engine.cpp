@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -158,11 +159,22 @@ int make_plan(const group_vtable *vt, size_t n, int c_req, int L_req, plan_t &p,
     p.L = L;
     const size_t xyz_bytes = (size_t)3 * vt->el_words * 4;
     p.list_stride = align_up(n ? n : 1, 64);
-    // entries per lane: enough lanes (W*T) to put >= 4 waves on every SIMD, at most 128 each
+    // entries per lane S (<= 128; lane t of a window owns entries [t*S, (t+1)*S)).  All lanes do the
+    // same work and the device holds `resident` of them at once, so the lane count W*T should
+    // fill whole rounds: k rounds exactly for the smallest k that keeps S <= 128, or simply
+    // S = 128 once there are many rounds anyway.
     {
-        const double lanes_wanted = 256.0 * 4 * 4 * 64;
+        const double resident = (double)vt->accumulate_resident_lanes();
+        const double entries = (double)n * p.W;
         uint32_t S = 8;
-        while (S < 128 && (double)n * p.W / S > lanes_wanted) S <<= 1;
+        if (entries >= 8.0 * 128.0 * resident) {
+            S = 128;
+        } else if (entries > 8.0 * resident) {
+            uint32_t k = 1;
+            while (entries / (k * resident) > 128.0) ++k;
+            S = (uint32_t)std::ceil(entries / (k * resident));
+            while (S < 128 && (double)p.W * (double)((n + S - 1) / S) > k * resident) ++S;
+        }
         if (S_req > 0) S = (uint32_t)S_req;
         p.S = S;
         p.T = (uint32_t)((n + S - 1) / S);

@@ -85,6 +85,8 @@ struct group_vtable {
     void (*accumulate)(hipStream_t, const uint32_t* ends, const uint32_t* lists, size_t list_stride,
                        const uint32_t* bases_affine, uint32_t* buckets, uint32_t* part_first, uint32_t* part_last,
                        uint32_t* cont_bucket, int W, uint32_t B, uint32_t S, uint32_t T);
+    // lanes of k_accumulate the device holds at once (CUs x resident workgroups x workgroup size)
+    size_t (*accumulate_resident_lanes)();
     // closes the buckets that span several lanes; queue: fixup_queue_words(W*T) words, the
     // first two zeroed
     void (*accumulate_fixup)(hipStream_t, const uint32_t* ends, uint32_t* buckets, uint32_t* part_first,

@@ -1668,6 +1668,15 @@ void l_accumulate(hipStream_t st, const uint32_t* ends, const uint32_t* lists, s
     hipLaunchKernelGGL(k_accumulate, dim3(blocks_for((size_t)W * T)), dim3(TPB), 0, st, ends, lists, list_stride, bases,
                        buckets, part_first, part_last, cont_bucket, W, B, S, T);
 }
+size_t l_accumulate_resident_lanes() {
+    static const size_t lanes = [] {
+        int dev = 0, cus = 256, blocks = 0;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_accumulate, TPB, 0) != hipSuccess || blocks <= 0) blocks = 4;
+        return (size_t)cus * (size_t)blocks * TPB;
+    }();
+    return lanes;
+}
 void l_accumulate_fixup(hipStream_t st, const uint32_t* ends, uint32_t* buckets, uint32_t* part_first,
                         const uint32_t* part_last, const uint32_t* cont_bucket, uint32_t* queue, int W, uint32_t B,
                         uint32_t S, uint32_t T) {
@@ -1772,7 +1781,7 @@ void l_madd_bench(hipStream_t st, const uint32_t* pts, uint32_t* out, size_t nth
 
 const group_vtable g_vt = {
     GP::CURVE, GP::GROUP, FRW, EW, FQ::N, FR::BITS, GP::LIBFF_PROJECTIVE ? 1 : 0, FR::R,
-    l_import_bases, l_precompute_table, l_count, l_scatter, l_sort, l_accumulate, l_accumulate_fixup, l_reduce_segments, l_sum_butterfly, l_horner, l_sum_points,
+    l_import_bases, l_precompute_table, l_count, l_scatter, l_sort, l_accumulate, l_accumulate_resident_lanes, l_accumulate_fixup, l_reduce_segments, l_sum_butterfly, l_horner, l_sum_points,
     l_gen_bases_seq, l_export_affine, l_ffi_decode_points, l_ffi_decode_scalars, l_ffi_encode_point, l_disk_decode, l_fixed_base_exp, l_field_op, l_group_op, l_digits, l_mul_bench, l_madd_bench,
 };
 
