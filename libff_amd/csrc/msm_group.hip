@@ -334,7 +334,7 @@ __global__ void __launch_bounds__(SCAN_TPB) k_scan(uint32_t* __restrict__ counts
 //                   then chunk-wise LDS counting sort -> lists[w] (runs per fine bucket)
 // bucket index = |digit| - 1 = (coarse << FB) | fine, HB = min(10, c-1), FB = c-1-HB.
 constexpr int SORT_TPB = 1024;
-constexpr int SORT_TILE = 8192;     // entries per k_sort_coarse workgroup
+constexpr int SORT_TILE = 16384;    // entries per k_sort_coarse workgroup
 constexpr int SORT_CHUNK = 16384;   // entries per k_sort_fine chunk
 constexpr int SORT_MAX_HB = 10;
 constexpr int SORT_MAX_FB = 11;     // c <= 22
