@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Randomised parity soak: random group, size, scalar pattern, window size, base form and
+chunking; the engine (through the C ABI) against the CPU oracle.  Test infrastructure.
+
+  python tools/fuzz_parity.py --seconds 240 --seed 1
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import libff_amd  # noqa: E402
+from common import GROUPS, small_scalars_mont  # noqa: E402
+from oracle import port  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=120)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--max-n", type=int, default=4000)
+    args = ap.parse_args()
+    rng = np.random.default_rng(args.seed)
+    eng = libff_amd.Engine(0)
+    t_end = time.time() + args.seconds
+    it = 0
+    fails = 0
+    while time.time() < t_end:
+        name, curve, group = GROUPS[rng.integers(len(GROUPS))]
+        heavy = group == 2 or curve == 2
+        n = int(rng.integers(1, (args.max_n // 4 if heavy else args.max_n) + 1))
+        pattern = int(rng.integers(6))
+        sc = port.scalars_sha512(curve, int(rng.integers(1 << 30)), n)
+        if pattern == 1:      # witness-like: 0 / 1 / small / random
+            pick = rng.integers(0, 5, size=n)
+            sm = small_scalars_mont(port, curve, [0, 1, 2, 3])
+            for v in range(4):
+                sc[pick == v] = sm[v]
+        elif pattern == 2:    # one value repeated
+            sc[rng.random(n) < 0.8] = sc[0]
+        elif pattern == 3:    # all equal
+            sc[:] = sc[0]
+        elif pattern == 4:    # small scalars only
+            vals = [int(x) for x in rng.integers(0, 1 << 20, size=n)]
+            sc = small_scalars_mont(port, curve, vals)
+        first = int(rng.integers(0, 1 << 20))
+        bases = port.bases_seq(curve, group, n, first=first) if rng.random() < 0.6 else port.bases_r32(curve, group, n)
+        if pattern == 5 and n >= 4:   # equal and opposite bases, an infinite base
+            bases[1] = bases[0]
+            bases[2] = port.group_op(curve, group, 3, bases[0])
+            bases[3] = port.group_consts(curve, group)[1]
+        c = int(rng.choice([0, 0, 0, 2, 3, 5, 7, 9, 11, 13, 16]))
+        form = int(rng.integers(2))
+        chunks = int(rng.choice([1, 1, 2, 3, 8]))
+        want = port.multi_exp(curve, group, bases, sc, port.BDLO12_SIGNED, 1, chunks=4, omp=True)
+        got = eng.multi_exp(curve, group, bases, sc, base_form=form, window_bits=c, chunks=chunks)
+        it += 1
+        if not (got == want).all():
+            fails += 1
+            print(f"MISMATCH it={it} {name} n={n} pattern={pattern} c={c} form={form} chunks={chunks} first={first}", flush=True)
+        if it % 50 == 0:
+            print(f"[fuzz] {it} cases, {fails} mismatches", flush=True)
+    print(f"[fuzz] done: {it} cases, {fails} mismatches")
+    return 1 if fails else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
