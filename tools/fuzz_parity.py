@@ -24,13 +24,44 @@ def main():
     ap.add_argument("--seconds", type=float, default=120)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--max-n", type=int, default=4000)
+    ap.add_argument("--mode", choices=("multi_exp", "precomputed"), default="multi_exp")
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
     eng = libff_amd.Engine(0)
     t_end = time.time() + args.seconds
     it = 0
     fails = 0
-    while time.time() < t_end:
+    import tempfile
+    tmpdir = tempfile.mkdtemp(prefix="amdmsm_fuzz_")
+    while args.mode == "precomputed" and time.time() < t_end:
+        # multi_exp_stream_with_precompute: device-built table == oracle table, file entry == oracle
+        name, curve, group = GROUPS[rng.integers(len(GROUPS))]
+        heavy = group == 2 or curve == 2
+        n = int(rng.integers(1, (300 if heavy else 1500) + 1))
+        c = int(rng.integers(3, 14))
+        D = libff_amd.precompute_num_digits(curve, c) + int(rng.integers(2))
+        sc = port.scalars_sha512(curve, int(rng.integers(1 << 30)), n)
+        if rng.random() < 0.3:
+            sc[rng.random(n) < 0.7] = sc[0]
+        bases = port.bases_seq(curve, group, n, first=int(rng.integers(0, 1 << 20)))
+        if n >= 3 and rng.random() < 0.3:
+            bases[2] = port.group_consts(curve, group)[1]
+        tab = eng.precompute_table(curve, group, bases, c, num_digits=D)
+        ok = (tab == port.precompute_table(curve, group, bases, c, num_digits=D)).all()
+        want = port.multi_exp_precompute(curve, group, tab, sc, c, num_digits=D)
+        if D == libff_amd.precompute_num_digits(curve, c):
+            path = os.path.join(tmpdir, "t.bin")
+            open(path, "wb").write(port.disk_write(curve, group, tab).tobytes())
+            got = eng.multi_exp_stream_with_precompute_file(curve, group, path, sc, c,
+                                                            chunk_points=int(rng.choice([0, 0, 17, 256])))
+            ok = ok and (got == want).all()
+        it += 1
+        if not ok:
+            fails += 1
+            print(f"MISMATCH it={it} {name} n={n} c={c} D={D}", flush=True)
+        if it % 25 == 0:
+            print(f"[fuzz precomputed] {it} cases, {fails} mismatches", flush=True)
+    while args.mode == "multi_exp" and time.time() < t_end:
         name, curve, group = GROUPS[rng.integers(len(GROUPS))]
         heavy = group == 2 or curve == 2
         n = int(rng.integers(1, (args.max_n // 4 if heavy else args.max_n) + 1))
