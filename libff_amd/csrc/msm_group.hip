@@ -1104,15 +1104,14 @@ __global__ void __launch_bounds__(64) k_horner(const uint32_t* __restrict__ wind
     if (threadIdx.x == 0) store_out(out, res, form);
 }
 
-__global__ void k_sum_points(const uint32_t* __restrict__ pts, int k, int form, uint32_t* __restrict__ out) {
-    if (gtid() != 0) return;
-    Jac<E> res, x;
-    jac_set_inf(res);
-    for (int i = 0; i < k; ++i) {
-        load_jac(x, pts + (size_t)i * XYZW);
-        jac_add(res, res, x);
-    }
-    store_out(out, res, form);
+// plain sum of k engine-Jacobian points by one wave: the Horner chain with no doublings, i.e. on
+// lane-split coordinates (partials of chunked / multi-GPU calls, multiexp.tcc:681-687)
+__global__ void __launch_bounds__(64) k_sum_points(const uint32_t* __restrict__ pts, int k, int form,
+                                                   uint32_t* __restrict__ out) {
+    Jac<E> res;
+    if (k <= 0) jac_set_inf(res);
+    else horner_chain(res, pts, k, 0, nullptr);
+    if (threadIdx.x == 0) store_out(out, res, form);
 }
 
 // ------------------------------------------------------------ base import
