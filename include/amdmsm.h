@@ -179,7 +179,8 @@ int amdmsm_msm_device(amdmsm_ctx *ctx, int curve, int group, const void *d_bases
  * create_precompute_file_for_config -- and amdmsm_msm_precomputed_device is
  * multi_exp_precompute_from_fifo (multiexp_stream.tcc:124-162) on it.  num_digits =
  * amdmsm_precompute_num_digits() reproduces the reference; one more digit where
- * c divides Fr::num_bits keeps the final carry. */
+ * c divides Fr::num_bits keeps the final carry.  Inputs with n * num_digits >= 2^31 are split
+ * into ranges of points internally. */
 int amdmsm_precompute_bases_device(amdmsm_ctx *ctx, int curve, int group, const void *d_bases_affine,
                                    size_t n, size_t c, size_t num_digits, void *d_table, void *stream);
 int amdmsm_msm_precomputed_device(amdmsm_ctx *ctx, int curve, int group, const void *d_table,

@@ -50,6 +50,7 @@ struct amdmsm_ctx {
     int last_slot = 0;
     bool timing = false;
     hipEvent_t ev[AMDMSM_MAX_PHASES + 1] = {};   // probes
+    void *chunk_partials = nullptr;               // a few points, for calls split into several MSMs
     std::string err;
     std::mutex mu;
 };
@@ -440,6 +441,7 @@ void amdmsm_ctx_destroy(amdmsm_ctx *ctx) {
         for (auto &e : ctx->ev) {
             if (e) (void)hipEventDestroy(e);
         }
+        if (ctx->chunk_partials) (void)hipFree(ctx->chunk_partials);
         if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     }
     delete ctx;
@@ -569,8 +571,35 @@ int amdmsm_msm_precomputed_device(amdmsm_ctx *ctx, int curve, int group, const v
     if (opts) o = *opts;
     else o.out_form = AMDMSM_OUT_LIBFF;
     o.window_bits = (int)c;
-    return msm_device_impl(ctx, vt, (const uint32_t *)d_table, (const uint32_t *)d_scalars, n, (uint32_t *)d_out_xyz, &o,
-                           (int)num_digits);
+    // one sorted list holds n * num_digits entries and is indexed with 31 bits: larger inputs are
+    // split into ranges of points whose partial results are summed (multiexp.tcc:663-687 shape)
+    // (AMDMSM_TABLE_MAX_ENTRIES lowers the limit so that tests can reach the split path)
+    static const size_t max_entries = getenv("AMDMSM_TABLE_MAX_ENTRIES") ? (size_t)atoll(getenv("AMDMSM_TABLE_MAX_ENTRIES"))
+                                                                         : ((size_t)1 << 31) - 1;
+    const size_t max_pts = std::max<size_t>(1, max_entries / num_digits);
+    if (n <= max_pts) {
+        return msm_device_impl(ctx, vt, (const uint32_t *)d_table, (const uint32_t *)d_scalars, n, (uint32_t *)d_out_xyz,
+                               &o, (int)num_digits);
+    }
+    constexpr size_t MAX_PARTS = 64;
+    const size_t parts = (n + max_pts - 1) / max_pts;
+    if (parts > MAX_PARTS) return fail(ctx, AMDMSM_ERR_TOO_LARGE, "input too large for one call");
+    const size_t xyz_bytes = (size_t)vt->el_words * 12, aff_bytes = (size_t)vt->el_words * 8;
+    if (!ctx->chunk_partials) HIP_TRY(ctx, hipMalloc(&ctx->chunk_partials, MAX_PARTS * 3 * 24 * 2 * 4));
+    const int form = o.out_form;
+    o.out_form = AMDMSM_OUT_JACOBIAN;
+    hipStream_t st = o.stream ? (hipStream_t)o.stream : ctx->stream;
+    for (size_t k = 0; k < parts; ++k) {
+        const size_t lo = k * max_pts, cnt = std::min(max_pts, n - lo);
+        const int rc = msm_device_impl(ctx, vt, (const uint32_t *)((const char *)d_table + lo * num_digits * aff_bytes),
+                                       (const uint32_t *)((const char *)d_scalars + lo * (size_t)vt->fr_words * 4), cnt,
+                                       (uint32_t *)((char *)ctx->chunk_partials + k * xyz_bytes), &o, (int)num_digits);
+        if (rc) return rc;
+    }
+    vt->sum_points(st, (const uint32_t *)ctx->chunk_partials, (int)parts, form, (uint32_t *)d_out_xyz);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(st));   // the partials buffer is shared by the context
+    return AMDMSM_OK;
 }
 
 int amdmsm_import_bases_device(amdmsm_ctx *ctx, int curve, int group, const void *d_src_xyz, size_t stride_bytes,

@@ -524,6 +524,34 @@ def test_window_groups_experimental():
         assert r.returncode == 0 and "groups-ok" in r.stdout, r.stderr[-2000:]
 
 
+def test_precomputed_split_of_oversized_inputs():
+    """A precomputed-table call whose n * num_digits entries exceed what one sorted list can
+    index is split into point ranges (engine.cpp); the limit is lowered through the environment
+    so that 3000 points already need several parts.  Child process: the knob is read once."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import libff_amd; from oracle import port\n"
+        "curve, group, n, c = 0, 1, 3000, 9\n"
+        "D = libff_amd.precompute_num_digits(curve, c) + 1\n"
+        "b = port.bases_seq(curve, group, n, first=3); s = port.scalars_sha512(curve, 5, n)\n"
+        "e = libff_amd.Engine(0); z = libff_amd.sizes(curve, group)\n"
+        "tab = e.precompute_table(curve, group, b, c, num_digits=D)\n"
+        "d_src = e.malloc(tab.nbytes); d_tab = e.malloc(tab.shape[0] * z['affine_bytes'])\n"
+        "d_sc = e.malloc(s.nbytes); d_out = e.malloc(z['g_bytes'])\n"
+        "e.h2d(d_src, tab); e.h2d(d_sc, s)\n"
+        "e.import_bases_device(curve, group, d_src, tab.strides[0], 1, tab.shape[0], d_tab)\n"
+        "e.msm_precomputed_device(curve, group, d_tab, d_sc, n, c, D, d_out, out_form=libff_amd.OUT_AFFINE)\n"
+        "e.synchronize(); out = np.zeros(z['g_bytes'] // 8, dtype=np.uint64); e.d2h(out, d_out)\n"
+        "want = port.multi_exp(curve, group, b, s, port.BDLO12_SIGNED, 1, chunks=4, omp=True)\n"
+        "assert (out == want).all(); print('split-ok')\n"
+    ) % (REPO, os.path.join(REPO, "tests"))
+    env = dict(os.environ, AMDMSM_TABLE_MAX_ENTRIES="20000")   # 3000 * 30 entries -> 5 parts
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "split-ok" in r.stdout, r.stderr[-2000:]
+
+
 def test_lane_split_arithmetic_selftest(tmp_path):
     """tools/wide_test.hip: the lane-split field / Jacobian arithmetic of the Horner chain
     (libff_amd/csrc/wide.cuh) against the per-lane implementation on thousands of random and
