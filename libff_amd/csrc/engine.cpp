@@ -111,9 +111,9 @@ struct plan_t {
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-// Window size.  Measured on MI355X (alt_bn128 G1; the ratios carry over to the other fields):
+// Window size.  Measured on MI355X (alt_bn128 G1; the other fields scale both terms alike):
 // sort + accumulation cost ~0.137 ns per (point, window) entry and the bucket reduction
-// ~0.8 ns per bucket.  A top window that keeps only 2..8 significant bits concentrates all of
+// ~0.8 ns per bucket, with a latency floor.  A top window that keeps only 2..8 significant bits concentrates all of
 // its n entries in a handful of buckets, which the second sort level (one workgroup per coarse
 // bin) processes almost serially -- such c are penalised rather than forbidden.
 int choose_c(const group_vtable *vt, size_t n) {
@@ -123,7 +123,13 @@ int choose_c(const group_vtable *vt, size_t n) {
     for (int c = 2; c <= 22; ++c) {
         const int W = (vt->fr_bits + 2 + c - 1) / c;
         const double B = (double)((size_t)1 << (c - 1));
-        double cost = (double)W * ((double)n * 0.137 + B * 0.8);
+        // the reduction's dependent chain takes ~0.65 ms however few buckets there are (measured
+        // from 2^16 points up; below that the small-c regime with tiny bucket sets is faster)
+        // (wider coordinates: the reduction kernels spill, a bucket costs relatively more)
+        const double wide = (vt->fq_words > 8 || vt->el_words > vt->fq_words) ? 1.5 : 1.0;
+        double reduce_cost = (double)W * B * 0.8 * wide;
+        if (n >= 65536) reduce_cost = std::max(reduce_cost, 0.65e6);
+        double cost = (double)W * (double)n * 0.137 + reduce_cost;
         const int top_bits = vt->fr_bits + 1 - (W - 1) * c;   // bit positions left for the top window
         if (top_bits >= 2 && top_bits <= 8) cost += (double)n * 3.0 / (double)(1 << (top_bits - 1));
         if (cost < best) {
