@@ -3,12 +3,20 @@
 
   python bench.py --gpus N --steps K --warmup W [--log2n L] [--curve alt_bn128]
 
-One "step" = one full MSM (libff::multi_exp) over this rank's shard of synthetic
-(scalar, base) pairs that are already resident in HBM.  With N > 1 (launched by
-torch.distributed.run, one rank per GPU) every rank owns a contiguous range of the
-input (weak scaling: 2^L points per GPU), reduces it to one partial point and the
-partials are exchanged with one RCCL all-gather and summed on every rank
-(multiexp.tcc:663-687 with rank == chunk).  value = total scalar-muls/s of the job.
+One "step" = one full MSM (libff::multi_exp) over synthetic (scalar, base) pairs that are
+already resident in HBM.
+
+N = 1   `value` = BASELINE configs[1]: alt_bn128 G1, 2^20 points, one MSM after the other.
+        Inside `config.legs` (the driver keeps `config`): the 2^26-point size of the metric,
+        the end-to-end (scalars over PCIe, resident bases) and host-entry (everything from host
+        memory) timings of SURVEY.md §8(d), back-to-back MSMs in flight, precomputed multiples.
+N > 1   one rank per GPU (started by torch.distributed.run -- by the caller, or by this script
+        itself when WORLD_SIZE is unset).  `value` = BASELINE configs[3]: alt_bn128 G1, 2^26 points
+        in TOTAL, range-sharded (multiexp.tcc:663-687 with rank == chunk): every rank reduces
+        its 2^26/N points to one partial point, one RCCL all-gather of the partials, local sum
+        -> "scaling": "strong".  `config.legs` adds configs[4] (bw6_761 G1 + bls12_377 G2, 2^24
+        points in total each, issued together on two streams per rank), the weak-scaling figure
+        (2^20 points per GPU) and the same 2^26 MSM on rank 0 alone.
 
 The JSON line also carries
   roofline      bucket-accumulation kernel (dominant): algorithmic bytes per launch
@@ -16,23 +24,18 @@ The JSON line also carries
                 mean duration from HIP events on the launch stream, against the 8 TB/s
                 HBM peak.  The path is integer-ALU bound; the fraction is small by nature.
   cpu_baseline  libff's own multi_exp (oracle/_ref, "reference") or the C restatement
-                ("port") timed on the host cores of this box on a bounded sample.
+                ("port") timed on the host cores of this box.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
-import libff_amd  # noqa: E402
-from libff_amd.distributed import ShardedMsm  # noqa: E402
 
 CURVES = {"alt_bn128": 0, "bls12_377": 1, "bw6_761": 2, "bls12_381": 3}
 # SURVEY.md §8(d): one scalar + one affine base per scalar-mul
@@ -52,6 +55,61 @@ FR_MODULUS = {
     2: 0x1AE3A4617C510EAC63B05C06CA1493B1A22D9F300F5138F1EF3622FBA094800170B5D44300000008508C00000000001,
     3: 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001,
 }
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--log2n", type=int, default=int(os.environ.get("AMDMSM_BENCH_LOG2N", "0")),
+                    help="points of the `value` workload: per GPU at N = 1 (default 20), in TOTAL at N > 1 (default 26)")
+    ap.add_argument("--curve", default="alt_bn128", choices=sorted(CURVES))
+    ap.add_argument("--group", type=int, default=1, choices=(1, 2))
+    ap.add_argument("--window-bits", type=int, default=0)
+    ap.add_argument("--cpu-log2n", type=int, default=20, help="size of the cpu_baseline workload")
+    ap.add_argument("--extra-log2n", type=int, default=int(os.environ.get("AMDMSM_BENCH_EXTRA_LOG2N", "26")),
+                    help="N = 1: also time this size (config.legs.points_2pXX); 0 disables")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-legs", action="store_true", help="only the `value` workload (profiling runs)")
+    ap.add_argument("--pipeline", type=int, default=int(os.environ.get("AMDMSM_BENCH_PIPELINE", "1")),
+                    help="MSMs in flight in the timed region (1 = strictly one after the other, which is "
+                         "what `value` and the roofline kernel timings are quoted on)")
+    ap.add_argument("--also-pipelined", type=int, default=3,
+                    help="N = 1: also measure the same workload with this many MSMs in flight; 0 disables")
+    ap.add_argument("--precomputed-c", type=int, default=16,
+                    help="N = 1: also time the precomputed-multiples MSM (multi_exp_stream_with_precompute's algorithm "
+                         "on an HBM-resident table of [2^(jc)]P) with this window size; 0 disables")
+    ap.add_argument("--config4-log2n", type=int, default=24, help="N > 1: total points of the configs[4] leg; 0 disables")
+    return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks as fresh child
+    processes (this parent never touches the GPU) and pass rank 0's JSON line through."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    r = subprocess.run(cmd, env=env)
+    sys.exit(r.returncode)
+
+
+ARGS = parse_args()
+if ARGS.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    self_launch(ARGS)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import libff_amd  # noqa: E402
+from libff_amd.distributed import ShardedMsm, shard_range  # noqa: E402
 
 
 def random_scalars(curve, n, device, seed):
@@ -94,7 +152,7 @@ def random_scalars(curve, n, device, seed):
 
 def pmc_traffic(curve_name, group, log2n, window_bits):
     """HBM bytes per k_accumulate launch from the committed rocprofv3 PMC passes
-    (profiles/r*_pmc_*.json: separate FETCH_SIZE / WRITE_SIZE runs of this very command,
+    (profiles/r*_pmc*.json: separate FETCH_SIZE / WRITE_SIZE runs of this very command,
     gfx950 correction 2*FETCH + WRITE, see the file), or None when no pass matches the workload."""
     import glob
 
@@ -112,70 +170,405 @@ def pmc_traffic(curve_name, group, log2n, window_bits):
     return best
 
 
-def cpu_baseline(curve, group, log2n_sample):
-    """Time the CPU path on this box: the reference's multi_exp<BDLO12_signed, special> when
-    oracle/_ref/libff_ref.so is present, else the C restatement; all host cores, one range
-    per core (multiexp.tcc:667-679)."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(curve, group, log2n):
+    """libff's CPU path on this box, on the headline workload (2^log2n points, SHA512_rng scalars,
+    bases (i+1)G in special form): multi_exp<BDLO12_signed, special> with chunks = 1 (what the
+    reference's own profiler measures, profile_multiexp.cpp:184-207) and the best of
+    chunks in {cores/4, cores/2, cores} (OpenMP over ranges, multiexp.tcc:667-679) after a
+    warm-up call that spins the thread pool up.  oracle/_ref/libff_ref.so = the reference
+    itself ("reference"); the C restatement otherwise ("port")."""
     cores = os.cpu_count() or 1
     os.environ.setdefault("OMP_NUM_THREADS", str(cores))
-    n = 1 << log2n_sample
+    n = 1 << log2n
     from oracle import ref
 
     if ref.available():
         kind, be = "reference", ref
         be.lib()
-        bases = be.bases_seq(curve, group, n)
-        scalars = be.scalars_sha512(curve, 0, n)
-        _, secs = be.multi_exp(curve, group, bases, scalars, be.BDLO12_SIGNED, be.FORM_SPECIAL, chunks=cores,
-                               want_time=True)
+
+        def run(b, s, chunks):
+            _, secs = be.multi_exp(curve, group, b, s, be.BDLO12_SIGNED, be.FORM_SPECIAL, chunks=chunks, want_time=True)
+            return secs
     else:
         from oracle import port
 
         kind, be = "port", port
         be.build()
-        bases = be.bases_seq(curve, group, n)
-        scalars = be.scalars_sha512(curve, 0, n)
-        t0 = time.perf_counter()
-        be.multi_exp(curve, group, bases, scalars, be.BDLO12_SIGNED, be.FORM_SPECIAL, chunks=cores, omp=True)
-        secs = time.perf_counter() - t0
-    return {"value": n / secs, "unit": "scalar-muls/s", "cores": cores, "kind": kind,
-            "sample": f"first 2^{log2n_sample} (scalar, base) pairs of the workload family (SHA512_rng scalars, "
-                      f"bases (i+1)G), multi_exp<BDLO12_signed, special>, chunks={cores} (OpenMP), {secs:.2f} s"}
+
+        def run(b, s, chunks):
+            t0 = time.perf_counter()
+            be.multi_exp(curve, group, b, s, be.BDLO12_SIGNED, be.FORM_SPECIAL, chunks=chunks, omp=chunks > 1)
+            return time.perf_counter() - t0
+
+    bases = be.bases_seq(curve, group, n)
+    scalars = be.scalars_sha512(curve, 0, n)
+    run(bases[:1 << 14], scalars[:1 << 14], cores)   # OpenMP warm-up
+    multi = {}
+    for chunks in sorted({max(1, cores // 4), max(1, cores // 2), cores}):
+        multi[chunks] = min(run(bases, scalars, chunks) for _ in range(2))
+    best = min(multi, key=multi.get)
+    # chunks = 1 is one core for ~n / 45k seconds: a quarter of the workload keeps the default run short
+    n1 = n if n <= (1 << 18) else n // 4
+    t1 = run(bases[:n1], scalars[:n1], 1)
+    return {"value": n / multi[best], "unit": "scalar-muls/s", "cores": min(best, cores), "kind": kind,
+            "cpu": cpu_model(), "host_cores": cores,
+            "sample": f"2^{log2n} (scalar, base) pairs of the workload family (SHA512_rng scalars, bases (i+1)G, special "
+                      f"form), multi_exp<BDLO12_signed, special>; chunks={best} (OpenMP), best of "
+                      f"{ {c: round(t, 3) for c, t in multi.items()} } s after a warm-up call",
+            "single_core": {"value": n1 / t1, "unit": "scalar-muls/s", "cores": 1,
+                            "sample": f"chunks=1 (profile_multiexp.cpp:184-207) on the first {n1} pairs, {t1:.2f} s"}}
+
+
+class Timer:
+    """barrier + synchronize on both sides, max over ranks (the bench contract)."""
+
+    def __init__(self, world, dev):
+        self.world, self.dev = world, dev
+
+    def fence(self):
+        torch.cuda.synchronize()
+        if self.world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(self, seconds):
+        if self.world > 1:
+            tt = torch.tensor([seconds], dtype=torch.float64, device=self.dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return float(tt.item())
+        return seconds
+
+
+def gen_inputs(eng, curve, group, first, n, dev, seed):
+    sz = libff_amd.sizes(curve, group)
+    bases = torch.empty((max(n, 1), sz["affine_bytes"] // 8), dtype=torch.int64, device=dev)
+    eng.gen_bases_seq_device(curve, group, first, n, bases.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    scalars = random_scalars(curve, max(n, 1), dev, seed)
+    torch.cuda.synchronize()
+    return bases, scalars
+
+
+def timed_msm(tm, eng, msm, bases, scalars, n, steps, warmup, window_bits=0, want_phases=True):
+    """W warm-up steps, then exactly K timed steps; returns (seconds, per-step phase dicts)."""
+    for _ in range(max(warmup, msm.depth if warmup else 0)):
+        msm.run(bases, scalars, n, libff_amd.OUT_LIBFF, window_bits=window_bits)
+    msm.synchronize()
+    tm.fence()
+    phases, pending = [], []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        _, slot = msm.run(bases, scalars, n, libff_amd.OUT_LIBFF, window_bits=window_bits)
+        if want_phases:
+            pending.append(slot)
+            # a slot's events are re-recorded when the slot is reused: read a step's HIP-event timings
+            # before the step `depth` later is enqueued (depth 1: right away, one MSM at a time)
+            while len(pending) >= msm.depth:
+                phases.append(eng.get_timings(pending.pop(0)))
+    while pending:
+        phases.append(eng.get_timings(pending.pop(0)))
+    msm.synchronize()
+    tm.fence()
+    elapsed = tm.max_over_ranks(time.perf_counter() - t0)
+    return elapsed, phases
+
+
+def roofline_of(curve_name, curve, group, n_launch, plan, acc_ms, log2n_for_pmc):
+    algo_bytes = ALGO_BYTES[(curve, group)] * n_launch
+    achieved = algo_bytes / (acc_ms * 1e-3) / 1e9
+    fq_products = FQ_PRODUCTS_PER_MADD[group if not (curve == 2) else 1]
+    lane_instr = float(n_launch) * plan["num_windows"] * fq_products * 4 * FQ_LIMBS[curve] ** 2
+    mac_rate = lane_instr / (acc_ms * 1e-3)
+    return {
+        "bound": "hbm",
+        "kernel": "k_accumulate (bucket accumulation)",
+        "achieved": achieved,
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBS,
+        "traffic": pmc_traffic(curve_name, group, log2n_for_pmc, plan["c"]) if log2n_for_pmc else None,
+        "algorithmic_bytes_per_launch": algo_bytes,
+        "kernel_ms": acc_ms,
+        "note": "integer-ALU bound path (no MFMA); HBM fraction is small by construction",
+        "mac_issue": {"achieved": mac_rate / 1e12, "peak": MAC_PAIR_PEAK / 1e12, "unit": "T lane-instr/s",
+                      "frac": mac_rate / MAC_PAIR_PEAK,
+                      "what": "v_mad_u64_u32 + v_addc_co_u32 issues of the Montgomery products in k_accumulate "
+                              "(upper bound: every list entry counted as a full mixed addition) against the pair's "
+                              "measured issue rate at 4 waves/SIMD"},
+    }
+
+
+def mean_phases(phases):
+    return {k: float(np.mean([p[k] for p in phases])) for k in phases[0]} if phases else {}
+
+
+def single_gpu(args, tm, eng, dev, curve, group):
+    log2n = args.log2n or 20
+    n = 1 << log2n
+    plan = libff_amd.plan(curve, group, n, args.window_bits)
+    sz = libff_amd.sizes(curve, group)
+    bases, scalars = gen_inputs(eng, curve, group, 0, n, dev, 1234)
+    msm = ShardedMsm(eng, curve, group, depth=max(1, args.pipeline))
+    eng.set_timing(True)
+    elapsed, phases = timed_msm(tm, eng, msm, bases, scalars, n, args.steps, args.warmup, args.window_bits)
+    acc = float(np.mean([p["accumulate_ms"] for p in phases]))
+    legs = {}
+
+    if not args.no_legs and args.also_pipelined > 1 and msm.depth == 1:
+        pm = ShardedMsm(eng, curve, group, depth=args.also_pipelined)
+        kp = max(args.steps, 2 * pm.depth)
+        ep, _ = timed_msm(tm, eng, pm, bases, scalars, n, kp, pm.depth, args.window_bits, want_phases=False)
+        legs["pipelined"] = {"msms_in_flight": pm.depth, "steps": kp, "value": n * kp / ep, "unit": "scalar-muls/s",
+                             "ms_per_step": ep / kp * 1e3,
+                             "note": "consecutive MSMs on alternating streams / workspace slots: the few-wave tail of one "
+                                     "overlaps the bulk kernels of the next; `value` stays the one-at-a-time figure"}
+        msm = ShardedMsm(eng, curve, group, depth=1)
+
+    # ---- SURVEY §8(d) "end-to-end": scalars cross PCIe inside the timed region, bases resident
+    #      (amdmsm_register_bases), result back on the host; and the plain host entry where the
+    #      bases (libff (X, Y, Z) records, 96 B) cross PCIe and are imported on every call
+    if not args.no_legs:
+        h_bases = eng.gen_bases_seq(curve, group, n, first=0)     # libff special-form records on the host
+        h_scalars = np.ascontiguousarray(scalars.cpu().numpy()).view(np.uint64)
+
+        def host_calls(k):
+            for _ in range(2):
+                eng.multi_exp(curve, group, h_bases, h_scalars, base_form=libff_amd.multi_exp_base_form_special,
+                              out_form=libff_amd.OUT_LIBFF)
+            t0 = time.perf_counter()
+            for _ in range(k):
+                eng.multi_exp(curve, group, h_bases, h_scalars, base_form=libff_amd.multi_exp_base_form_special,
+                              out_form=libff_amd.OUT_LIBFF)
+            return (time.perf_counter() - t0) / k
+
+        kh = max(args.steps, 5)
+        t_host = host_calls(kh)
+        handle = eng.register_bases(curve, group, h_bases, libff_amd.multi_exp_base_form_special)
+        t_e2e = host_calls(kh)
+        eng.unregister_bases(handle)
+        legs["end_to_end"] = {"value": n / t_e2e, "unit": "scalar-muls/s", "ms_per_step": t_e2e * 1e3, "steps": kh,
+                              "what": "amdmsm_multi_exp on host vectors with the bases registered (resident in HBM): "
+                                      f"{n * sz['fr_bytes'] >> 20} MiB of scalars H2D from pageable memory + MSM + result D2H "
+                                      "per step -- the proving-key use case"}
+        legs["host_entry"] = {"value": n / t_host, "unit": "scalar-muls/s", "ms_per_step": t_host * 1e3, "steps": kh,
+                              "what": "amdmsm_multi_exp, everything from pageable host memory on every call: "
+                                      f"{n * sz['g_bytes'] >> 20} MiB of (X, Y, Z) bases + {n * sz['fr_bytes'] >> 20} MiB of "
+                                      "scalars H2D, base import, MSM (bases travel while the scalars are sorted)"}
+        del h_bases, h_scalars
+
+    # ---- fixed bases with precomputed multiples (multi_exp_stream_with_precompute, HBM-resident) ----
+    if not args.no_legs and args.precomputed_c:
+        pc = args.precomputed_c
+        D = libff_amd.precompute_num_digits(curve, pc)
+        stream = torch.cuda.current_stream().cuda_stream
+        table = torch.empty((n * D, sz["affine_bytes"] // 8), dtype=torch.int64, device=dev)
+        tb = time.perf_counter()
+        eng.precompute_bases_device(curve, group, bases.data_ptr(), n, pc, D, table.data_ptr(), stream=stream)
+        torch.cuda.synchronize()
+        build_s = time.perf_counter() - tb
+        out_pt = torch.zeros(sz["g_bytes"] // 8, dtype=torch.int64, device=dev)
+        for _ in range(2):
+            eng.msm_precomputed_device(curve, group, table.data_ptr(), scalars.data_ptr(), n, pc, D, out_pt.data_ptr())
+        eng.synchronize()
+        tm.fence()
+        kq = max(args.steps, 4)
+        tq = time.perf_counter()
+        for _ in range(kq):
+            eng.msm_precomputed_device(curve, group, table.data_ptr(), scalars.data_ptr(), n, pc, D, out_pt.data_ptr())
+        phq = eng.get_timings()
+        eng.synchronize()
+        tm.fence()
+        eq = time.perf_counter() - tq
+        legs["precomputed"] = {"window_bits": pc, "multiples_per_base": D, "table_gib": table.numel() * 8 / 2**30,
+                               "table_build_ms": build_s * 1e3, "steps": kq, "value": n * kq / eq,
+                               "unit": "scalar-muls/s", "ms_per_step": eq / kq * 1e3, "phases_ms_last": phq,
+                               "note": "libff's multi_exp_stream_with_precompute algorithm (one bucket set over the table "
+                                       "[2^(jc)]P_i, no doublings) with the table resident in HBM; a different reference "
+                                       "entry point than `value`'s multi_exp"}
+        del table
+
+    # ---- the other size of the metric (2^26), outside the main timed region ----
+    roof2 = None
+    if not args.no_legs and args.extra_log2n and args.extra_log2n != log2n:
+        n2 = 1 << args.extra_log2n
+        del bases, scalars
+        torch.cuda.empty_cache()
+        bases2, scalars2 = gen_inputs(eng, curve, group, 0, n2, dev, 4321)
+        k2 = 4
+        e2, ph2 = timed_msm(tm, eng, msm, bases2, scalars2, n2, k2, 1)
+        p2 = libff_amd.plan(curve, group, n2)
+        acc2 = float(np.mean([p["accumulate_ms"] for p in ph2]))
+        legs[f"points_2p{args.extra_log2n}"] = {
+            "workload": f"{args.curve} G{group} MSM, 2^{args.extra_log2n} points on one GPU (the north-star target size)",
+            "steps": k2, "value": n2 * k2 / e2, "unit": "scalar-muls/s", "ms_per_step": e2 / k2 * 1e3,
+            "window_bits": p2["c"], "num_windows": p2["num_windows"], "phases_ms": mean_phases(ph2)}
+        roof2 = roofline_of(args.curve, curve, group, n2, p2, acc2, args.extra_log2n)
+        del bases2, scalars2
+
+    roof = roofline_of(args.curve, curve, group, n, plan, acc, log2n)
+    if roof2 is not None:
+        roof[f"at_2p{args.extra_log2n}"] = {k: roof2[k] for k in ("achieved", "frac", "traffic", "algorithmic_bytes_per_launch",
+                                                                  "kernel_ms", "mac_issue")}
+    out = {
+        "metric": "G1 MSM throughput (scalar-muls/sec)" if group == 1 else "G2 MSM throughput (scalar-muls/sec)",
+        "value": n * args.steps / elapsed,
+        "unit": "scalar-muls/s",
+        "n_gpus": 1,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{args.curve} G{group} MSM, 2^{log2n} points, 1 GPU (BASELINE configs[1]); bases (i+1)G affine "
+                        f"resident in HBM, uniform random scalars in [0,r) (Montgomery residues as libff holds them)",
+            "points_per_gpu": n,
+            "total_points": n,
+            "window_bits": plan["c"],
+            "num_windows": plan["num_windows"],
+            "parallelism": "1 GPU",
+            "msms_in_flight": msm.depth,
+            "phases_ms": mean_phases(phases),
+            "legs": legs,
+        },
+        "roofline": roof,
+    }
+    return out
+
+
+def multi_gpu(args, tm, eng, dev, rank, world, curve, group):
+    """configs[3]: 2^26 points in total, range-sharded; plus configs[4] and the weak-scaling leg."""
+    log2n = args.log2n or 26
+    total = 1 << log2n
+    lo, hi = shard_range(total, world, rank)
+    n = hi - lo
+    plan = libff_amd.plan(curve, group, n, args.window_bits)
+    bases, scalars = gen_inputs(eng, curve, group, lo, n, dev, 1234 + rank)   # bases (lo + i + 1) * G
+    msm = ShardedMsm(eng, curve, group, depth=1)
+    eng.set_timing(True)
+    elapsed, phases = timed_msm(tm, eng, msm, bases, scalars, n, args.steps, args.warmup, args.window_bits)
+    acc = float(np.mean([p["accumulate_ms"] for p in phases]))
+    legs = {}
+
+    # the same total on rank 0 alone (what one GPU does with the whole input), the others wait
+    if not args.no_legs:
+        del bases, scalars
+        torch.cuda.empty_cache()
+        if rank == 0:
+            b1, s1 = gen_inputs(eng, curve, group, 0, total, dev, 99)
+            st1 = torch.cuda.Stream(dev)
+            o1 = torch.zeros(libff_amd.sizes(curve, group)["g_bytes"] // 8, dtype=torch.int64, device=dev)
+            k1 = 3
+            eng.msm_device(curve, group, b1.data_ptr(), s1.data_ptr(), total, o1.data_ptr(),
+                           out_form=libff_amd.OUT_LIBFF, stream=st1.cuda_stream)
+            st1.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(k1):
+                eng.msm_device(curve, group, b1.data_ptr(), s1.data_ptr(), total, o1.data_ptr(),
+                               out_form=libff_amd.OUT_LIBFF, stream=st1.cuda_stream)
+            st1.synchronize()
+            e1 = time.perf_counter() - t0
+            legs["same_total_on_one_gpu"] = {"value": total * k1 / e1, "unit": "scalar-muls/s", "ms_per_step": e1 / k1 * 1e3,
+                                             "steps": k1, "what": f"the whole 2^{log2n}-point MSM on rank 0's GPU alone "
+                                             "(strong-scaling reference for `value`)"}
+            del b1, s1
+            torch.cuda.empty_cache()
+        tm.fence()
+
+        # weak scaling: 2^20 points per GPU
+        nw = 1 << 20
+        bw, sw = gen_inputs(eng, curve, group, rank * nw, nw, dev, 555 + rank)
+        kw = max(args.steps, 10)
+        ew, _ = timed_msm(tm, eng, msm, bw, sw, nw, kw, 2, want_phases=False)
+        legs["weak_2p20_per_gpu"] = {"value": nw * world * kw / ew, "unit": "scalar-muls/s", "ms_per_step": ew / kw * 1e3,
+                                     "steps": kw, "scaling": "weak", "points_per_gpu": nw}
+        del bw, sw
+
+        # configs[4]: bw6_761 G1 + bls12_377 G2, 2^24 points in total each, issued together
+        if args.config4_log2n:
+            t4 = 1 << args.config4_log2n
+            lo4, hi4 = shard_range(t4, world, rank)
+            n4 = hi4 - lo4
+            eng2 = libff_amd.Engine(eng.device)   # second context: its own stream and workspace
+            jobs = []
+            for e, (cv, gp) in ((eng, (2, 1)), (eng2, (1, 2))):
+                b4, s4 = gen_inputs(e, cv, gp, lo4, n4, dev, 777 + rank)
+                jobs.append((ShardedMsm(e, cv, gp, depth=1), b4, s4))
+
+            def both():
+                for m, b4, s4 in jobs:   # asynchronous: the two MSMs (and their all-gathers) are in flight together
+                    m.run(b4, s4, n4, libff_amd.OUT_LIBFF)
+
+            both()
+            for m, _, _ in jobs:
+                m.synchronize()
+            tm.fence()
+            k4 = max(2, min(args.steps, 5))
+            t0 = time.perf_counter()
+            for _ in range(k4):
+                both()
+            for m, _, _ in jobs:
+                m.synchronize()
+            tm.fence()
+            e4 = tm.max_over_ranks(time.perf_counter() - t0)
+            legs["config4_bw6_761_g1_plus_bls12_377_g2"] = {
+                "value": 2 * t4 * k4 / e4, "unit": "scalar-muls/s", "ms_per_step": e4 / k4 * 1e3, "steps": k4,
+                "what": f"BASELINE configs[4]: bw6_761 G1 MSM + bls12_377 G2 MSM, 2^{args.config4_log2n} points in total each "
+                        f"({n4} per rank), both issued together on two streams per rank; a step = both MSMs incl. their "
+                        "all-gathers; value counts the scalar-muls of both"}
+            del jobs
+            eng2.close()
+
+    out = {
+        "metric": "G1 MSM throughput (scalar-muls/sec)" if group == 1 else "G2 MSM throughput (scalar-muls/sec)",
+        "value": total * args.steps / elapsed,
+        "unit": "scalar-muls/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "u32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{args.curve} G{group} MSM, 2^{log2n} points in total over {world} GPUs (BASELINE configs[3]): "
+                        f"rank r owns the contiguous range [r*n/N, (r+1)*n/N) of bases (i+1)G (affine, resident in its HBM) "
+                        "and uniform random scalars; one partial point per rank, RCCL all-gather, local sum",
+            "points_per_gpu": n,
+            "total_points": total,
+            "window_bits": plan["c"],
+            "num_windows": plan["num_windows"],
+            "parallelism": f"range-sharded x{world} (multiexp.tcc:663-687 with rank = chunk), all-gather of partial points "
+                           "+ local sum",
+            "msms_in_flight": 1,
+            "phases_ms": mean_phases(phases),
+            "legs": legs,
+        },
+        "roofline": roofline_of(args.curve, curve, group, n, plan, acc, 0),
+    }
+    return out
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--log2n", type=int, default=int(os.environ.get("AMDMSM_BENCH_LOG2N", "20")),
-                    help="points per GPU = 2^log2n")
-    ap.add_argument("--curve", default="alt_bn128", choices=sorted(CURVES))
-    ap.add_argument("--group", type=int, default=1, choices=(1, 2))
-    ap.add_argument("--window-bits", type=int, default=0)
-    ap.add_argument("--cpu-sample-log2n", type=int, default=18)
-    ap.add_argument("--extra-log2n", type=int, default=int(os.environ.get("AMDMSM_BENCH_EXTRA_LOG2N", "26")),
-                    help="also time this size after the main region (reported under 'also'); 0 disables")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--pipeline", type=int, default=int(os.environ.get("AMDMSM_BENCH_PIPELINE", "1")),
-                    help="MSMs in flight in the timed region (1 = strictly one after the other, which is "
-                         "what `value` and the roofline kernel timings are quoted on)")
-    ap.add_argument("--also-pipelined", type=int, default=3,
-                    help="after the timed region, also measure the same workload with this many MSMs in flight "
-                         "(reported under 'pipelined'); 0 disables")
-    ap.add_argument("--precomputed-c", type=int, default=16,
-                    help="also time the precomputed-multiples MSM (multi_exp_stream_with_precompute's algorithm on an "
-                         "HBM-resident table of [2^(jc)]P) with this window size (reported under 'precomputed'); "
-                         "0 disables")
-    args = ap.parse_args()
-
+    args = ARGS
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
@@ -184,232 +577,23 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-
     curve, group = CURVES[args.curve], args.group
-    n = 1 << args.log2n
-    sz = libff_amd.sizes(curve, group)
     eng = libff_amd.Engine(local_rank)
-    plan = libff_amd.plan(curve, group, n, args.window_bits)
-
-    # ---- synthetic inputs, resident in HBM before the timed region ----------
-    stream = torch.cuda.current_stream().cuda_stream
-    bases = torch.empty((n, sz["affine_bytes"] // 8), dtype=torch.int64, device=dev)
-    eng.gen_bases_seq_device(curve, group, rank * n, n, bases.data_ptr(), stream=stream)   # (rank*n + i + 1) * G
-    scalars = random_scalars(curve, n, dev, seed=1234 + rank)
-    torch.cuda.synchronize()
-
-    msm = ShardedMsm(eng, curve, group, depth=max(1, args.pipeline))
-    eng.set_timing(True)
-
-    def step():
-        return msm.run(bases, scalars, n, libff_amd.OUT_LIBFF, window_bits=args.window_bits)
-
-    for _ in range(max(args.warmup, msm.depth if args.warmup else 0)):
-        step()
-    msm.synchronize()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    acc_ms = []
-    phases = []
-    pending = []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        _, slot = step()
-        pending.append(slot)
-        # read the HIP-event timings of a step only once a later step is already enqueued
-        while len(pending) >= msm.depth:
-            t = eng.get_timings(pending.pop(0))
-            acc_ms.append(t["accumulate_ms"])
-            phases.append(t)
-    while pending:
-        t = eng.get_timings(pending.pop(0))
-        acc_ms.append(t["accumulate_ms"])
-        phases.append(t)
-    msm.synchronize()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-
-    # ---- same workload with several MSMs in flight (throughput of back-to-back MSMs) ----
-    pipelined = None
-    if args.also_pipelined > 1 and msm.depth == 1:
-        pm = ShardedMsm(eng, curve, group, depth=args.also_pipelined)
-        for _ in range(pm.depth):
-            pm.run(bases, scalars, n, libff_amd.OUT_LIBFF, window_bits=args.window_bits)
-        pm.synchronize()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        kp = max(args.steps, 2 * pm.depth)
-        tp = time.perf_counter()
-        for _ in range(kp):
-            pm.run(bases, scalars, n, libff_amd.OUT_LIBFF, window_bits=args.window_bits)
-        pm.synchronize()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        ep = time.perf_counter() - tp
-        if world > 1:
-            tt = torch.tensor([ep], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            ep = float(tt.item())
-        pipelined = {"msms_in_flight": pm.depth, "steps": kp, "value": n * world * kp / ep, "unit": "scalar-muls/s",
-                     "ms_per_step": ep / kp * 1e3,
-                     "note": "consecutive MSMs issued on alternating streams / workspace slots so the few-wave "
-                             "tail of one overlaps the bulk kernels of the next; per-kernel timings are not "
-                             "comparable with the un-overlapped ones, so `value` stays the depth-1 figure"}
-        msm = ShardedMsm(eng, curve, group, depth=1)
-
-    # ---- fixed bases with precomputed multiples (multi_exp_stream_with_precompute, HBM-resident) ----
-    precomputed = None
-    if args.precomputed_c:
-        pc = args.precomputed_c
-        D = libff_amd.precompute_num_digits(curve, pc)
-        table = torch.empty((n * D, sz["affine_bytes"] // 8), dtype=torch.int64, device=dev)
-        tb = time.perf_counter()
-        eng.precompute_bases_device(curve, group, bases.data_ptr(), n, pc, D, table.data_ptr(), stream=stream)
-        torch.cuda.synchronize()
-        build_s = time.perf_counter() - tb
-        out_pt = torch.zeros(sz["g_bytes"] // 8, dtype=torch.int64, device=dev)
-        for _ in range(2):
-            eng.msm_precomputed_device(curve, group, table.data_ptr(), scalars.data_ptr(), n, pc, D, out_pt.data_ptr(),
-                                       stream=stream)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        kq = max(args.steps, 4)
-        tq = time.perf_counter()
-        for _ in range(kq):
-            eng.msm_precomputed_device(curve, group, table.data_ptr(), scalars.data_ptr(), n, pc, D, out_pt.data_ptr(),
-                                       stream=stream)
-        phq = eng.get_timings()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        eq = time.perf_counter() - tq
-        if world > 1:
-            tt = torch.tensor([eq], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            eq = float(tt.item())
-        precomputed = {"window_bits": pc, "multiples_per_base": D, "table_gib": table.numel() * 8 / 2**30,
-                       "table_build_ms": build_s * 1e3, "steps": kq, "value": n * world * kq / eq,
-                       "unit": "scalar-muls/s", "ms_per_step": eq / kq * 1e3, "phases_ms_last": phq,
-                       "note": "libff's multi_exp_stream_with_precompute algorithm (one bucket set over the table "
-                               "[2^(jc)]P_i, no doublings) with the table resident in HBM; per-rank results are not "
-                               "combined in this leg; a different reference entry point than `value`'s multi_exp"}
-        del table
-
-    # ---- second size of the metric (2^26 by default), outside the main timed region ----
-    also = None
-    if args.extra_log2n and args.extra_log2n != args.log2n:
-        n2 = 1 << args.extra_log2n
-        del bases, scalars
-        torch.cuda.empty_cache()
-        bases2 = torch.empty((n2, sz["affine_bytes"] // 8), dtype=torch.int64, device=dev)
-        eng.gen_bases_seq_device(curve, group, rank * n2, n2, bases2.data_ptr(), stream=stream)
-        scalars2 = random_scalars(curve, n2, dev, seed=4321 + rank)
-        torch.cuda.synchronize()
-        for _ in range(msm.depth):
-            msm.run(bases2, scalars2, n2, libff_amd.OUT_LIBFF)
-        msm.synchronize()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        k2 = 4
-        t1 = time.perf_counter()
-        for _ in range(k2):
-            _, slot2 = msm.run(bases2, scalars2, n2, libff_amd.OUT_LIBFF)
-        ph2 = eng.get_timings(slot2)
-        msm.synchronize()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        e2 = time.perf_counter() - t1
-        if world > 1:
-            tt = torch.tensor([e2], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            e2 = float(tt.item())
-        p2 = libff_amd.plan(curve, group, n2)
-        also = {"workload": f"{args.curve} G{group} MSM, 2^{args.extra_log2n} points per GPU", "steps": k2,
-                "value": n2 * world * k2 / e2, "unit": "scalar-muls/s", "ms_per_step": e2 / k2 * 1e3,
-                "window_bits": p2["c"], "num_windows": p2["num_windows"], "phases_ms_last": ph2}
-        del bases2, scalars2
-
+    tm = Timer(world, dev)
+    if world == 1:
+        out = single_gpu(args, tm, eng, dev, curve, group)
+    else:
+        out = multi_gpu(args, tm, eng, dev, rank, world, curve, group)
     if rank == 0:
-        total_points = n * world * args.steps
-        value = total_points / elapsed
-        acc = float(np.mean(acc_ms))
-        algo_bytes = ALGO_BYTES[(curve, group)] * n
-        achieved = algo_bytes / (acc * 1e-3) / 1e9
-        mean_phase = {k: float(np.mean([p[k] for p in phases])) for k in phases[0]}
-        fq_products = FQ_PRODUCTS_PER_MADD[group if not (curve == 2) else 1]
-        lane_instr = float(n) * plan["num_windows"] * fq_products * 4 * FQ_LIMBS[curve] ** 2
-        mac_rate = lane_instr / (acc * 1e-3)
-        mac_issue = {"achieved": mac_rate / 1e12, "peak": MAC_PAIR_PEAK / 1e12, "unit": "T lane-instr/s",
-                     "frac": mac_rate / MAC_PAIR_PEAK,
-                     "what": "v_mad_u64_u32 + v_addc_co_u32 issues of the Montgomery products in k_accumulate "
-                             "(upper bound: every list entry counted as a full mixed addition) against the pair's "
-                             "measured issue rate at 4 waves/SIMD"}
-        out = {
-            "metric": "G1 MSM throughput (scalar-muls/sec)" if group == 1 else "G2 MSM throughput (scalar-muls/sec)",
-            "value": value,
-            "unit": "scalar-muls/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "u32",
-            "data": "synthetic",
-            "config": {
-                "workload": f"{args.curve} G{group} MSM, 2^{args.log2n} points per GPU, bases (i+1)G affine resident "
-                            f"in HBM, uniform random scalars in [0,r) (Montgomery residues as libff holds them)",
-                "points_per_gpu": n,
-                "total_points": n * world,
-                "window_bits": plan["c"],
-                "num_windows": plan["num_windows"],
-                "parallelism": f"range-sharded x{world}, all-gather of partial points + local sum",
-                "msms_in_flight": msm.depth,
-            },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": "k_accumulate (bucket accumulation)",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": pmc_traffic(args.curve, group, args.log2n, plan["c"]),
-                "algorithmic_bytes_per_launch": algo_bytes,
-                "kernel_ms": acc,
-                "note": "integer-ALU bound path (no MFMA); HBM fraction is small by construction",
-                "mac_issue": mac_issue,
-            },
-            "phases_ms": mean_phase,
-        }
-        if pipelined is not None:
-            out["pipelined"] = pipelined
-        if precomputed is not None:
-            out["precomputed"] = precomputed
-        if also is not None:
-            out["also"] = also
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(curve, group, min(args.cpu_sample_log2n, args.log2n))
+                out["cpu_baseline"] = cpu_baseline(curve, group, args.cpu_log2n)
             except Exception as e:  # the baseline is a reported extra; never lose the GPU line to it
                 out["cpu_baseline"] = {"value": None, "unit": "scalar-muls/s", "cores": 0, "kind": "port",
                                        "sample": f"failed: {e!r}"}
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -10,6 +10,9 @@
  *   amdmsm_multi_exp_filter_one_zero
  *                             libff::multi_exp_filter_one_zero, multiexp.hpp:78-88,
  *                             multiexp.tcc:690-757
+ *   amdmsm_multi_exp_multi    the same multi_exp with libff's chunk split (multiexp.tcc:655-687)
+ *                             mapped to the GPUs of one node
+ *   amdmsm_register_bases     (extension) keeps a base vector resident in HBM between calls
  *   amdmsm_batch_to_special   libff::batch_to_special<G>, multiexp.hpp:136-141,
  *                             multiexp.tcc:949-974
  *   amdmsm_multi_exp_stream   libff::multi_exp_stream (bases streamed in the on-disk format),
@@ -122,6 +125,33 @@ int amdmsm_multi_exp_filter_one_zero(amdmsm_ctx *ctx, int curve, int group,
 int amdmsm_batch_to_special(amdmsm_ctx *ctx, int curve, int group, void *elems_xyz,
                             size_t stride_bytes, size_t n);
 
+/* Resident base vectors.  A prover calls multi_exp with the same base vector (its proving key,
+ * libsnark r1cs_gg_ppzksnark_proving_key) proof after proof; the reference re-reads it from host
+ * memory every time (multiexp.tcc:643-688 takes const iterators).  amdmsm_register_bases imports
+ * the vector once (libff records -> compact affine in HBM, Montgomery's trick for normal-form
+ * bases) and from then on every amdmsm_multi_exp[_multi|_filter_one_zero] call whose base range
+ * lies inside [bases_xyz, bases_xyz + n*stride) with the same stride and form reads the resident
+ * copy: only the scalars cross PCIe.  The caller promises not to modify a registered vector
+ * without amdmsm_invalidate_bases (any registration overlapping [host_ptr, host_ptr + bytes);
+ * NULL = all) or amdmsm_unregister_bases.  AMDMSM_BASE_CACHE_MB=<MiB> in the environment makes
+ * the host entry points register what they see automatically (LRU within the cap); off by default
+ * because of that promise. */
+int amdmsm_register_bases(amdmsm_ctx *ctx, int curve, int group, const void *bases_xyz,
+                          size_t base_stride_bytes, int base_form, size_t n, uint64_t *handle);
+int amdmsm_unregister_bases(amdmsm_ctx *ctx, uint64_t handle);
+int amdmsm_invalidate_bases(amdmsm_ctx *ctx, const void *host_ptr, size_t bytes);
+
+/* multi_exp over several GPUs of one node from ONE process (what a C++ host such as libsnark
+ * has): libff's own range split (multiexp.tcc:655-687, `one = total / chunks`, the last range
+ * takes the remainder) with chunk = device.  ctxs[k] (one context per device, or several
+ * contexts on one device) reduces its range on its own device from its own host thread; the
+ * ndev partial points travel to ctxs[0]'s device (hipMemcpyPeerAsync over xGMI) and are summed
+ * there (multiexp.tcc:681-687).  Resident bases are honoured per context: register each range
+ * with its context. */
+int amdmsm_multi_exp_multi(amdmsm_ctx *const *ctxs, int ndev, int curve, int group,
+                           const void *bases_xyz, size_t base_stride_bytes, int base_form,
+                           const void *scalars, size_t n, void *out_xyz, const amdmsm_opts *opts);
+
 /* Streaming MSM: bases are pulled through `read` in libff's on-disk format -- binary,
  * Montgomery form, uncompressed, i.e. consecutive group_write<encoding_binary, form_montgomery,
  * compression_off> records (curve_serialization.tcc:78-101; what profile_multiexp.cpp:100-150
@@ -186,6 +216,12 @@ int amdmsm_precompute_bases_device(amdmsm_ctx *ctx, int curve, int group, const 
 int amdmsm_msm_precomputed_device(amdmsm_ctx *ctx, int curve, int group, const void *d_table,
                                   const void *d_scalars, size_t n, size_t c, size_t num_digits,
                                   void *d_out_xyz, const amdmsm_opts *opts);
+/* the device-resident form of amdmsm_multi_exp_multi: d_bases_affine[k] / d_scalars[k] / counts[k]
+ * live on ctxs[k]'s device; the result is written to d_out_xyz_dev0 on ctxs[0]'s device
+ * (opts->stream orders that final sum on device 0; the call returns after it has completed) */
+int amdmsm_msm_device_multi(amdmsm_ctx *const *ctxs, int ndev, int curve, int group,
+                            const void *const *d_bases_affine, const void *const *d_scalars,
+                            const size_t *counts, void *d_out_xyz_dev0, const amdmsm_opts *opts);
 /* sum of k engine-Jacobian partial results (multi-GPU / chunk combination, multiexp.tcc:681-687) */
 int amdmsm_sum_points_device(amdmsm_ctx *ctx, int curve, int group, const void *d_points_jacobian,
                              int k, int out_form, void *d_out_xyz, void *stream);

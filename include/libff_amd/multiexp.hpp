@@ -12,9 +12,16 @@
 // specialisations generic in GroupT (multiexp.tcc:276-381, 507-633).  The specialisations
 // below fix GroupT/FieldT as well, are therefore more specialised, and are picked for
 //   alt_bn128_G1/G2, bls12_377_G1/G2, bls12_381_G1/G2, bw6_761_G1/G2
-// while every other (group, method) pair keeps the reference's CPU body.  multi_exp itself
-// (chunk split + serial sum, multiexp.tcc:643-688) and multi_exp_filter_one_zero (:690-757) are
-// the reference's own code and simply call into the engine per chunk.  Fixed-base
+// while every other (group, method) pair keeps the reference's CPU body.  The outer
+// libff::multi_exp (chunk split + OpenMP + serial sum, multiexp.tcc:643-688) is explicitly
+// specialised for the same (group, method, form) combinations: `chunks` is the caller's CPU
+// thread count (libsnark passes omp_get_max_threads()), and cutting one 2^20-point GPU MSM into
+// that many small ones would multiply the fixed costs (launch chain, bucket reduction, Horner)
+// and serialise them on the context -- so the whole range goes to the engine as ONE MSM, split
+// only across the GPUs configured with libff_amd::set_devices (multiexp.tcc:655-687 with
+// chunk = device).  multi_exp_filter_one_zero (:690-757) is specialised likewise: the 0 / 1
+// classification runs on the device and the three statistics lines are printed as the
+// reference prints them.  Fixed-base
 // batch_exp / batch_exp_with_coeff (multiexp.tcc:874-947) get non-template overloads for the
 // same groups (chosen over the templates when the call deduces its arguments, as libsnark's
 // key generators do); explicit batch_exp<T, FieldT>(...) calls keep the CPU body.
@@ -30,36 +37,102 @@
 
 #include <amdmsm.h>
 
+#include <cstdio>
+#include <cstdlib>
 #include <mutex>
 #include <stdexcept>
 #include <string>
 #include <type_traits>
+#include <vector>
 
 namespace libff_amd
 {
 
-/// One engine context per process (device chosen by set_device before first use).
-inline int &device_ordinal()
+/// Engine contexts of the process: one per configured device, created on first use.
+/// set_device(d) = one GPU (default: device 0); set_devices({..}) = multi_exp splits large
+/// inputs across these GPUs (amdmsm_multi_exp_multi); AMDMSM_DEVICES="0,1,2,3" or "all" in the
+/// environment does the same without touching the host program.
+struct context_pool {
+    std::mutex mu;
+    std::vector<int> devices;
+    std::vector<amdmsm_ctx *> ctxs;
+    bool created = false;
+};
+inline context_pool &pool()
 {
-    static int dev = 0;
-    return dev;
+    static context_pool p;
+    return p;
 }
-inline void set_device(int device) { device_ordinal() = device; }
-
-inline amdmsm_ctx *default_context()
+inline void set_devices(const std::vector<int> &devices)
 {
-    static amdmsm_ctx *ctx = nullptr;
-    static std::once_flag once;
-    std::call_once(once, [] {
-        const int rc = amdmsm_ctx_create(device_ordinal(), &ctx);
-        if (rc != AMDMSM_OK) {
-            ctx = nullptr;
-            throw std::runtime_error(
-                std::string("libff_amd: cannot create the MSM engine: ") +
-                amdmsm_strerror(rc));
+    context_pool &p = pool();
+    std::lock_guard<std::mutex> lock(p.mu);
+    if (p.created) {
+        throw std::runtime_error(
+            "libff_amd: set_devices after the engine has been used");
+    }
+    p.devices = devices;
+}
+inline void set_device(int device) { set_devices(std::vector<int>(1, device)); }
+
+inline const std::vector<amdmsm_ctx *> &contexts()
+{
+    context_pool &p = pool();
+    std::lock_guard<std::mutex> lock(p.mu);
+    if (!p.created) {
+        if (p.devices.empty()) {
+            const char *env = std::getenv("AMDMSM_DEVICES");
+            if (env && std::string(env) == "all") {
+                for (int d = 0; d < amdmsm_device_count(); ++d) {
+                    p.devices.push_back(d);
+                }
+            } else if (env && *env) {
+                std::string tok;
+                for (const char *c = env;; ++c) {
+                    if (*c == ',' || *c == 0) {
+                        if (!tok.empty()) {
+                            p.devices.push_back(std::atoi(tok.c_str()));
+                        }
+                        tok.clear();
+                        if (*c == 0) {
+                            break;
+                        }
+                    } else {
+                        tok.push_back(*c);
+                    }
+                }
+            }
+            if (p.devices.empty()) {
+                p.devices.push_back(0);
+            }
         }
-    });
-    return ctx;
+        for (const int d : p.devices) {
+            amdmsm_ctx *ctx = nullptr;
+            const int rc = amdmsm_ctx_create(d, &ctx);
+            if (rc != AMDMSM_OK) {
+                for (amdmsm_ctx *c : p.ctxs) {
+                    amdmsm_ctx_destroy(c);
+                }
+                p.ctxs.clear();
+                throw std::runtime_error(
+                    std::string("libff_amd: cannot create the MSM engine on "
+                                "device ") +
+                    std::to_string(d) + ": " + amdmsm_strerror(rc));
+            }
+            p.ctxs.push_back(ctx);
+        }
+        p.created = true;
+    }
+    return p.ctxs;
+}
+inline amdmsm_ctx *default_context() { return contexts().front(); }
+
+/// Inputs below this many points per device stay on one GPU (the fixed costs of an MSM --
+/// about a millisecond of latency-bound reduction -- outweigh the split).
+inline size_t &min_points_per_device()
+{
+    static size_t n = (size_t)1 << 18;
+    return n;
 }
 
 /// (curve, group) ids of the C ABI for a libff group type; specialised below
@@ -102,6 +175,129 @@ GroupT gpu_multi_exp_inner(
     return result;
 }
 
+/// The whole of libff::multi_exp (multiexp.tcc:643-688) for a routed group: one MSM on one
+/// GPU, or libff's range split with chunk = device when several devices are configured and
+/// the input is large enough.  `chunks` only keeps its "total < chunks -> no split" meaning
+/// for the device split; it never multiplies MSMs on one GPU.
+template<typename GroupT, typename FieldT, libff::multi_exp_base_form BaseForm>
+GroupT gpu_multi_exp(
+    typename std::vector<GroupT>::const_iterator vec_start,
+    typename std::vector<GroupT>::const_iterator vec_end,
+    typename std::vector<FieldT>::const_iterator scalar_start,
+    typename std::vector<FieldT>::const_iterator scalar_end,
+    const size_t chunks,
+    size_t *stats = nullptr)
+{
+    (void)scalar_end;
+    (void)chunks;
+    const size_t n = vec_end - vec_start;
+    const std::vector<amdmsm_ctx *> &ctxs = contexts();
+    size_t ndev = ctxs.size();
+    while (ndev > 1 && n / ndev < min_points_per_device()) {
+        --ndev;
+    }
+    GroupT result = GroupT::zero();
+    amdmsm_opts opts = {};
+    opts.out_form = AMDMSM_OUT_LIBFF;
+    const void *b = n ? static_cast<const void *>(&*vec_start) : nullptr;
+    const void *s = n ? static_cast<const void *>(&*scalar_start) : nullptr;
+    const int form = BaseForm == libff::multi_exp_base_form_special
+                         ? AMDMSM_FORM_SPECIAL
+                         : AMDMSM_FORM_NORMAL;
+    int rc;
+    if (stats) {
+        // counts come from device 0 over the whole scalar vector; the sum may still be split
+        rc = amdmsm_multi_exp_filter_one_zero(
+            ctxs[0], group_id<GroupT>::curve, group_id<GroupT>::group, b,
+            sizeof(GroupT), form, s, n, static_cast<void *>(&result.X), &opts,
+            stats);
+    } else if (ndev > 1) {
+        rc = amdmsm_multi_exp_multi(
+            ctxs.data(), (int)ndev, group_id<GroupT>::curve,
+            group_id<GroupT>::group, b, sizeof(GroupT), form, s, n,
+            static_cast<void *>(&result.X), &opts);
+    } else {
+        rc = amdmsm_multi_exp(
+            ctxs[0], group_id<GroupT>::curve, group_id<GroupT>::group, b,
+            sizeof(GroupT), form, s, n, static_cast<void *>(&result.X), &opts);
+    }
+    if (rc != AMDMSM_OK) {
+        throw std::runtime_error(
+            std::string("libff_amd: multi_exp failed: ") + amdmsm_strerror(rc) +
+            " (" + amdmsm_last_error(ctxs[0]) + ")");
+    }
+    return result;
+}
+
+/// multi_exp_filter_one_zero (multiexp.tcc:690-757): same block structure and the same three
+/// statistics lines; the classification itself runs on the device.
+template<typename GroupT, typename FieldT, libff::multi_exp_base_form BaseForm>
+GroupT gpu_multi_exp_filter_one_zero(
+    typename std::vector<GroupT>::const_iterator vec_start,
+    typename std::vector<GroupT>::const_iterator vec_end,
+    typename std::vector<FieldT>::const_iterator scalar_start,
+    typename std::vector<FieldT>::const_iterator scalar_end,
+    const size_t chunks)
+{
+    libff::enter_block("Process scalar vector");
+    size_t st[3] = {0, 0, 0};
+    const GroupT result = gpu_multi_exp<GroupT, FieldT, BaseForm>(
+        vec_start, vec_end, scalar_start, scalar_end, chunks, st);
+    const size_t total = st[0] + st[1] + st[2];
+    libff::print_indent();
+    printf(
+        "* Elements of w skipped: %zu (%0.2f%%)\n", st[0], 100. * st[0] / total);
+    libff::print_indent();
+    printf(
+        "* Elements of w processed with special addition: %zu (%0.2f%%)\n",
+        st[1],
+        100. * st[1] / total);
+    libff::print_indent();
+    printf(
+        "* Elements of w remaining: %zu (%0.2f%%)\n", st[2], 100. * st[2] / total);
+    libff::leave_block("Process scalar vector");
+    return result;
+}
+
+/// Keep a base vector (a proving key's query vector) resident in HBM: later multi_exp calls on
+/// `bases` -- or on sub-ranges of it -- send only the scalars over PCIe (amdmsm_register_bases).
+/// With several devices every device registers its own range of the split multi_exp will use.
+/// The vector must not be modified or reallocated until invalidate_bases(bases).
+template<typename GroupT>
+void register_bases(
+    const std::vector<GroupT> &bases, libff::multi_exp_base_form form)
+{
+    const std::vector<amdmsm_ctx *> &ctxs = contexts();
+    const size_t n = bases.size();
+    size_t ndev = ctxs.size();
+    while (ndev > 1 && n / ndev < min_points_per_device()) {
+        --ndev;
+    }
+    const size_t one = n / ndev;
+    for (size_t k = 0; k < ndev && n; ++k) {
+        const size_t lo = k * one, cnt = (k == ndev - 1) ? n - lo : one;
+        const int rc = amdmsm_register_bases(
+            ctxs[k], group_id<GroupT>::curve, group_id<GroupT>::group,
+            static_cast<const void *>(&bases[lo]), sizeof(GroupT),
+            form == libff::multi_exp_base_form_special ? AMDMSM_FORM_SPECIAL
+                                                       : AMDMSM_FORM_NORMAL,
+            cnt, nullptr);
+        if (rc != AMDMSM_OK) {
+            throw std::runtime_error(
+                std::string("libff_amd: register_bases failed: ") +
+                amdmsm_strerror(rc) + " (" + amdmsm_last_error(ctxs[k]) + ")");
+        }
+    }
+}
+template<typename GroupT> void invalidate_bases(const std::vector<GroupT> &bases)
+{
+    for (amdmsm_ctx *ctx : contexts()) {
+        amdmsm_invalidate_bases(
+            ctx, static_cast<const void *>(bases.data()),
+            bases.size() * sizeof(GroupT));
+    }
+}
+
 /// batch_exp / batch_exp_with_coeff (multiexp.tcc:874-947) on the device.  The window table
 /// libff built on the host (get_window_table, multiexp.tcc:809-846) is only read for its
 /// generator, powers_of_g[0][1] = g; the device rebuilds the table in HBM.
@@ -138,6 +334,34 @@ std::vector<GroupT> gpu_batch_exp(
 }
 
 } // namespace libff_amd
+
+/// Explicit specialisations of the outer libff::multi_exp / multi_exp_filter_one_zero function
+/// templates (multiexp.hpp:63-88) for one (group, method, form): must be visible before the
+/// first call that would instantiate the primary template, i.e. include this header wherever
+/// the reference header was included.
+#define LIBFF_AMD_ROUTE_OUTER(GROUP_T, FIELD_T, METHOD, FORM)                  \
+    template<>                                                                 \
+    inline GROUP_T multi_exp<GROUP_T, FIELD_T, METHOD, FORM>(                  \
+        std::vector<GROUP_T>::const_iterator vec_start,                        \
+        std::vector<GROUP_T>::const_iterator vec_end,                          \
+        std::vector<FIELD_T>::const_iterator scalar_start,                     \
+        std::vector<FIELD_T>::const_iterator scalar_end,                       \
+        const size_t chunks)                                                   \
+    {                                                                          \
+        return libff_amd::gpu_multi_exp<GROUP_T, FIELD_T, FORM>(               \
+            vec_start, vec_end, scalar_start, scalar_end, chunks);             \
+    }                                                                          \
+    template<>                                                                 \
+    inline GROUP_T multi_exp_filter_one_zero<GROUP_T, FIELD_T, METHOD, FORM>(  \
+        std::vector<GROUP_T>::const_iterator vec_start,                        \
+        std::vector<GROUP_T>::const_iterator vec_end,                          \
+        std::vector<FIELD_T>::const_iterator scalar_start,                     \
+        std::vector<FIELD_T>::const_iterator scalar_end,                       \
+        const size_t chunks)                                                   \
+    {                                                                          \
+        return libff_amd::gpu_multi_exp_filter_one_zero<GROUP_T, FIELD_T, FORM>( \
+            vec_start, vec_end, scalar_start, scalar_end, chunks);             \
+    }
 
 /// Route BDLO12 and BDLO12_signed of one (GroupT, FieldT) pair to the engine.
 #define LIBFF_AMD_ROUTE_GROUP(GROUP_T, FIELD_T, CURVE_ID, GROUP_ID)            \
@@ -189,6 +413,10 @@ std::vector<GroupT> gpu_batch_exp(
         }                                                                      \
     };                                                                         \
     }                                                                          \
+    LIBFF_AMD_ROUTE_OUTER(GROUP_T, FIELD_T, multi_exp_method_BDLO12_signed, multi_exp_base_form_normal)  \
+    LIBFF_AMD_ROUTE_OUTER(GROUP_T, FIELD_T, multi_exp_method_BDLO12_signed, multi_exp_base_form_special) \
+    LIBFF_AMD_ROUTE_OUTER(GROUP_T, FIELD_T, multi_exp_method_BDLO12, multi_exp_base_form_normal)         \
+    LIBFF_AMD_ROUTE_OUTER(GROUP_T, FIELD_T, multi_exp_method_BDLO12, multi_exp_base_form_special)        \
     inline std::vector<GROUP_T> batch_exp(                                     \
         const size_t scalar_size,                                              \
         const size_t window,                                                   \

@@ -11,6 +11,10 @@
  *                  bigint size: alt_bn128 Fr 32 B / Fq 32 B; bls12_377 Fr 32 B / Fq 48 B;
  *                  bw6_761 Fr 48 B / Fq 96 B
  *   G1 element     affine X || Y (alt_bn128 64 B, bls12_377 96 B, bw6_761 192 B); zero = (0, 1)
+ *   G2 element     the same over the twist's coordinate field (ffi.h:13-17, 55-59): alt_bn128
+ *                  128 B and bls12_377 192 B with Fq2 coordinates written c1 then c0 (extension
+ *                  coefficients highest-order first, ffi_serialization.tcc:19-54); bw6_761 G2 has
+ *                  Fq coordinates, 192 B
  *   bases_g1       n consecutive G1 elements, scalars_fr n consecutive Fr elements
  * Validation on read is the reference's (group_element_read, ffi_serialization.tcc:150-171):
  * exact sizes, every integer < its modulus, is_well_formed(), is_in_safe_subgroup().  On any
@@ -39,6 +43,17 @@ bool bls12_377_g1_multiexp(const void *bases_g1, size_t bases_g1_size, const voi
 
 bool bw6_761_g1_multiexp(const void *bases_g1, size_t bases_g1_size, const void *scalars_fr,
                          size_t scalars_fr_size, void *out_g1, size_t out_g1_size);
+
+/* G2 (same conventions; is_in_safe_subgroup as bls12_377_g2.cpp:461-473, bw6_761_g2.cpp:396-399,
+ * alt_bn128_g2.cpp:389-392) */
+bool alt_bn128_g2_multiexp(const void *bases_g2, size_t bases_g2_size, const void *scalars_fr,
+                           size_t scalars_fr_size, void *out_g2, size_t out_g2_size);
+
+bool bls12_377_g2_multiexp(const void *bases_g2, size_t bases_g2_size, const void *scalars_fr,
+                           size_t scalars_fr_size, void *out_g2, size_t out_g2_size);
+
+bool bw6_761_g2_multiexp(const void *bases_g2, size_t bases_g2_size, const void *scalars_fr,
+                         size_t scalars_fr_size, void *out_g2, size_t out_g2_size);
 
 #ifdef __cplusplus
 }

@@ -14,6 +14,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace amdmsm;
@@ -41,6 +42,25 @@ struct ws_slot {
     bool ev_valid = false;
 };
 
+// grow-only device buffer kept by the context between calls (host-buffer entry points)
+struct grow_buf {
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+
+// Base vector imported once and kept in HBM as compact affine records (amdmsm_register_bases):
+// the proving key of a prover that calls multi_exp with the same bases proof after proof.
+// Host-buffer calls whose base range lies inside [host, host + n*stride) use the resident copy.
+struct base_entry {
+    uint64_t id = 0;
+    int curve = 0, group = 0, form = 0;
+    const char *host = nullptr;
+    size_t n = 0, stride = 0;
+    void *d_aff = nullptr;
+    bool automatic = false;   // created by AMDMSM_BASE_CACHE, evictable
+    uint64_t last_use = 0;
+};
+
 struct amdmsm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -51,8 +71,16 @@ struct amdmsm_ctx {
     bool timing = false;
     hipEvent_t ev[AMDMSM_MAX_PHASES + 1] = {};   // probes
     void *chunk_partials = nullptr;               // a few points, for calls split into several MSMs
+    // host-buffer entry points: staging in HBM reused across calls, a second stream that brings
+    // the bases in while the scalars are already being sorted, and the resident base vectors
+    grow_buf hb_src, hb_aff, hb_sc, hb_out, hb_stats;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t bases_ready = nullptr, host_done = nullptr;
+    std::vector<base_entry> bases;
+    uint64_t next_base_id = 1, use_clock = 0;
+    float host_ms[4] = {};                        // last host-buffer call: scalars H2D, bases H2D+import, MSM, total
     std::string err;
-    std::mutex mu;
+    std::recursive_mutex mu;                      // one call at a time per context (entries nest)
 };
 
 namespace {
@@ -241,18 +269,6 @@ int ensure_ws(amdmsm_ctx *ctx, ws_slot &sl, size_t bytes) {
     return AMDMSM_OK;
 }
 
-struct dev_guard {
-    int prev = -1;
-    explicit dev_guard(int dev) {
-        (void)hipGetDevice(&prev);
-        if (prev != dev) (void)hipSetDevice(dev);
-        else prev = -1;
-    }
-    ~dev_guard() {
-        if (prev >= 0) (void)hipSetDevice(prev);
-    }
-};
-
 void record(amdmsm_ctx *ctx, ws_slot &sl, int idx, hipStream_t st) {
     if (ctx->timing) (void)hipEventRecord(sl.ev[idx], st);
 }
@@ -260,8 +276,16 @@ void record(amdmsm_ctx *ctx, ws_slot &sl, int idx, hipStream_t st) {
 // The whole single-GPU MSM on device-resident inputs.
 // table_digits > 0: d_bases is a precompute_table with that many multiples per scalar
 // (multi_exp_precompute_from_fifo, multiexp_stream.tcc:124-162: one bucket set, no doublings).
+// before_accumulate (optional): called once the bucket sort has been enqueued -- the sort reads
+// only the scalars, so a host entry uses it to bring the bases in on another stream meanwhile;
+// it returns an event the accumulation must wait for (or null).
+struct msm_hook {
+    int (*fn)(void *arg, hipEvent_t *wait_for) = nullptr;
+    void *arg = nullptr;
+};
 int msm_device_impl(amdmsm_ctx *ctx, const group_vtable *vt, const uint32_t *d_bases, const uint32_t *d_scalars,
-                    size_t n, uint32_t *d_out, const amdmsm_opts *opts, int table_digits = 0) {
+                    size_t n, uint32_t *d_out, const amdmsm_opts *opts, int table_digits = 0,
+                    const msm_hook *hook = nullptr) {
     hipStream_t st = (opts && opts->stream) ? (hipStream_t)opts->stream : ctx->stream;
     const int form = opts ? opts->out_form : AMDMSM_OUT_LIBFF;
     const int mont = (opts && opts->scalars_plain) ? 0 : 1;
@@ -311,6 +335,12 @@ int msm_device_impl(amdmsm_ctx *ctx, const group_vtable *vt, const uint32_t *d_b
     }
     HIP_TRY(ctx, hipMemsetAsync(buckets, 0, (size_t)p.W * p.B * vt->el_words * 16, st));
     for (int g = 0; g < p.G; ++g) HIP_TRY(ctx, hipMemsetAsync(ws + p.off_queue + g * p.queue_stride, 0, 8, st));
+    if (hook && hook->fn) {
+        hipEvent_t wait_for = nullptr;
+        rc = hook->fn(hook->arg, &wait_for);
+        if (rc) return rc;
+        if (wait_for) HIP_TRY(ctx, hipStreamWaitEvent(st, wait_for, 0));
+    }
     const size_t zzw = (size_t)vt->el_words * 4, xyzw = (size_t)vt->el_words * 3;   // words per XYZZ / Jacobian point
     const size_t M0 = p.B / p.L, cap1 = (M0 + p.L - 1) / p.L;
     uint32_t *pfirst = (uint32_t *)(ws + p.off_pfirst), *plast = (uint32_t *)(ws + p.off_plast);
@@ -408,6 +438,12 @@ int amdmsm_ctx_create(int device, amdmsm_ctx **out) {
             return AMDMSM_ERR_HIP;
         }
     }
+    if (hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->bases_ready, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->host_done, hipEventDisableTiming) != hipSuccess) {
+        delete ctx;
+        return AMDMSM_ERR_HIP;
+    }
     for (auto &sl : ctx->slots) {
         bool ok = hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) == hipSuccess;
         for (auto &e : sl.ev) ok = ok && hipEventCreate(&e) == hipSuccess;
@@ -448,6 +484,15 @@ void amdmsm_ctx_destroy(amdmsm_ctx *ctx) {
             if (e) (void)hipEventDestroy(e);
         }
         if (ctx->chunk_partials) (void)hipFree(ctx->chunk_partials);
+        for (grow_buf *b : {&ctx->hb_src, &ctx->hb_aff, &ctx->hb_sc, &ctx->hb_out, &ctx->hb_stats}) {
+            if (b->p) (void)hipFree(b->p);
+        }
+        for (auto &be : ctx->bases) {
+            if (be.d_aff) (void)hipFree(be.d_aff);
+        }
+        if (ctx->bases_ready) (void)hipEventDestroy(ctx->bases_ready);
+        if (ctx->host_done) (void)hipEventDestroy(ctx->host_done);
+        if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
         if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     }
     delete ctx;
@@ -496,7 +541,7 @@ int amdmsm_set_timing(amdmsm_ctx *ctx, int enable) {
 
 int amdmsm_set_pipeline_depth(amdmsm_ctx *ctx, int depth) {
     if (!ctx || depth < 1 || depth > MAX_SLOTS) return AMDMSM_ERR_BAD_ARG;
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     dev_guard g(ctx->device);
     HIP_TRY(ctx, hipDeviceSynchronize());
     ctx->depth = depth;
@@ -527,7 +572,7 @@ int amdmsm_get_timings(amdmsm_ctx *ctx, float ms[AMDMSM_MAX_PHASES]) {
     if (!ctx) return AMDMSM_ERR_BAD_ARG;                                  \
     const group_vtable *vt = find_vt(curve, group);                       \
     if (!vt) return fail(ctx, AMDMSM_ERR_UNSUPPORTED, "unknown curve/group"); \
-    std::lock_guard<std::mutex> lock_(ctx->mu);                           \
+    std::lock_guard<std::recursive_mutex> lock_(ctx->mu);                           \
     dev_guard guard_(ctx->device)
 
 int amdmsm_msm_device(amdmsm_ctx *ctx, int curve, int group, const void *d_bases_affine, const void *d_scalars,
@@ -573,6 +618,9 @@ int amdmsm_msm_precomputed_device(amdmsm_ctx *ctx, int curve, int group, const v
     GET_VT(ctx, curve, group);
     if (!d_out_xyz || (n && (!d_table || !d_scalars))) return fail(ctx, AMDMSM_ERR_BAD_ARG, "null pointer");
     if (c < 2 || c > 22 || num_digits < 1 || num_digits > 512) return fail(ctx, AMDMSM_ERR_BAD_ARG, "c / num_digits");
+    // more digits than the scalar has windows (+1 for the final carry) would only index multiples
+    // that are never selected; such a table layout is a caller error
+    if (num_digits > ((size_t)vt->fr_bits + c - 1) / c + 1) return fail(ctx, AMDMSM_ERR_BAD_ARG, "num_digits exceeds ceil(bits/c) + 1");
     amdmsm_opts o = {};
     if (opts) o = *opts;
     else o.out_form = AMDMSM_OUT_LIBFF;
@@ -738,53 +786,216 @@ int amdmsm_synchronize(amdmsm_ctx *ctx) {
 }
 
 // ------------------------------------------------------------ host entries
-int amdmsm_multi_exp(amdmsm_ctx *ctx, int curve, int group, const void *bases_xyz, size_t base_stride_bytes,
-                     int base_form, const void *scalars, size_t n, void *out_xyz, const amdmsm_opts *opts) {
-    GET_VT(ctx, curve, group);
-    if (!out_xyz || (n && (!bases_xyz || !scalars))) return fail(ctx, AMDMSM_ERR_BAD_ARG, "null pointer");
+}   // extern "C"
+
+namespace {
+
+int ensure_buf(amdmsm_ctx *ctx, grow_buf &b, size_t bytes) {
+    if (b.p && b.bytes >= bytes) return AMDMSM_OK;
+    if (b.p) {
+        HIP_TRY(ctx, hipDeviceSynchronize());
+        HIP_TRY(ctx, hipFree(b.p));
+        b.p = nullptr;
+        b.bytes = 0;
+    }
+    const size_t want = std::max<size_t>(bytes + bytes / 8, 256);
+    HIP_TRY(ctx, hipMalloc(&b.p, want));
+    b.bytes = want;
+    return AMDMSM_OK;
+}
+
+// resident compact-affine copy of the host range [bases, bases + n*stride), or null
+void *find_resident_bases(amdmsm_ctx *ctx, const group_vtable *vt, const void *bases, size_t stride, int form, size_t n) {
+    const char *lo = (const char *)bases;
+    for (auto &e : ctx->bases) {
+        if (e.curve != vt->curve || e.group != vt->group || e.form != form || e.stride != stride) continue;
+        if (lo < e.host || lo + n * stride > e.host + e.n * e.stride) continue;
+        const size_t off = (size_t)(lo - e.host);
+        if (off % stride) continue;
+        e.last_use = ++ctx->use_clock;
+        return (char *)e.d_aff + (off / stride) * (size_t)vt->el_words * 8;
+    }
+    return nullptr;
+}
+
+int register_bases_impl(amdmsm_ctx *ctx, const group_vtable *vt, const void *bases, size_t stride, int form, size_t n,
+                        bool automatic, uint64_t *handle) {
+    const size_t aff_bytes = (size_t)vt->el_words * 8;
+    base_entry e;
+    e.curve = vt->curve;
+    e.group = vt->group;
+    e.form = form;
+    e.host = (const char *)bases;
+    e.n = n;
+    e.stride = stride;
+    e.automatic = automatic;
+    HIP_TRY(ctx, hipMalloc(&e.d_aff, std::max<size_t>(n * aff_bytes, 256)));
+    int rc = ensure_buf(ctx, ctx->hb_src, n * stride);
+    if (rc == AMDMSM_OK) {
+        hipError_t he = hipMemcpyAsync(ctx->hb_src.p, bases, n * stride, hipMemcpyHostToDevice, ctx->stream);
+        if (he == hipSuccess) {
+            vt->import_bases(ctx->stream, (const uint32_t *)ctx->hb_src.p, stride / 4, form == AMDMSM_FORM_SPECIAL, n,
+                             (uint32_t *)e.d_aff);
+            he = hipGetLastError();
+        }
+        if (he == hipSuccess) he = hipStreamSynchronize(ctx->stream);
+        if (he != hipSuccess) rc = fail(ctx, AMDMSM_ERR_HIP, std::string("register_bases: ") + hipGetErrorString(he));
+    }
+    if (rc) {
+        (void)hipFree(e.d_aff);
+        return rc;
+    }
+    e.id = ctx->next_base_id++;
+    e.last_use = ++ctx->use_clock;
+    ctx->bases.push_back(e);
+    if (handle) *handle = e.id;
+    return AMDMSM_OK;
+}
+
+// AMDMSM_BASE_CACHE_MB=<cap>: host-buffer calls register the base vectors they see (keyed on
+// pointer, length, stride and form) up to <cap> MiB of HBM, least recently used first out.
+// Off by default: the caller must not modify a cached vector in place without
+// amdmsm_invalidate_bases (the reference re-reads the bases on every call).
+size_t auto_cache_cap_bytes() {
+    static const size_t cap = getenv("AMDMSM_BASE_CACHE_MB") ? (size_t)atoll(getenv("AMDMSM_BASE_CACHE_MB")) << 20 : 0;
+    return cap;
+}
+
+void drop_entry(amdmsm_ctx *ctx, size_t i) {
+    if (ctx->bases[i].d_aff) (void)hipFree(ctx->bases[i].d_aff);
+    ctx->bases.erase(ctx->bases.begin() + (long)i);
+}
+
+void *auto_cache_bases(amdmsm_ctx *ctx, const group_vtable *vt, const void *bases, size_t stride, int form, size_t n) {
+    const size_t cap = auto_cache_cap_bytes(), need = n * (size_t)vt->el_words * 8;
+    if (!cap || need > cap || n < 1024) return nullptr;
+    (void)hipStreamSynchronize(ctx->stream);
+    for (;;) {
+        size_t used = 0, lru = (size_t)-1;
+        for (size_t i = 0; i < ctx->bases.size(); ++i) {
+            const base_entry &e = ctx->bases[i];
+            if (!e.automatic) continue;
+            used += e.n * (size_t)vt->el_words * 8;
+            if (lru == (size_t)-1 || e.last_use < ctx->bases[lru].last_use) lru = i;
+        }
+        if (used + need <= cap || lru == (size_t)-1) break;
+        drop_entry(ctx, lru);
+    }
+    if (register_bases_impl(ctx, vt, bases, stride, form, n, true, nullptr) != AMDMSM_OK) return nullptr;
+    return ctx->bases.back().d_aff;
+}
+
+struct bases_upload {
+    amdmsm_ctx *ctx;
+    const group_vtable *vt;
+    const void *bases;
+    size_t stride, n;
+    int form;
+};
+// runs once the sort is enqueued: bases H2D + import on the copy stream (msm_hook)
+int upload_bases_hook(void *arg, hipEvent_t *wait_for) {
+    bases_upload &u = *(bases_upload *)arg;
+    amdmsm_ctx *ctx = u.ctx;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->hb_src.p, u.bases, u.n * u.stride, hipMemcpyHostToDevice, ctx->copy_stream));
+    u.vt->import_bases(ctx->copy_stream, (const uint32_t *)ctx->hb_src.p, u.stride / 4, u.form == AMDMSM_FORM_SPECIAL, u.n,
+                       (uint32_t *)ctx->hb_aff.p);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->bases_ready, ctx->copy_stream));
+    *wait_for = ctx->bases_ready;
+    return AMDMSM_OK;
+}
+
+// One MSM over host vectors, enqueued on the context stream; the result is left in
+// ctx->hb_out (and the scalar statistics in ctx->hb_stats) -- the caller copies it back.
+// Device buffers are the context's grow-only staging buffers: no allocation in steady state.
+int host_msm_enqueue(amdmsm_ctx *ctx, const group_vtable *vt, const void *bases_xyz, size_t stride, int base_form,
+                     const void *scalars, size_t n, const amdmsm_opts *opts, bool want_stats) {
     const size_t xyz_bytes = (size_t)vt->el_words * 12, aff_bytes = (size_t)vt->el_words * 8;
     const size_t fr_bytes = (size_t)vt->fr_words * 4;
-    if (base_stride_bytes == 0) base_stride_bytes = xyz_bytes;
-    if (base_stride_bytes % 16 || base_stride_bytes < xyz_bytes) return fail(ctx, AMDMSM_ERR_BAD_ARG, "base stride");
     hipStream_t st = ctx->stream;
-    void *d_src = nullptr, *d_aff = nullptr, *d_sc = nullptr, *d_out = nullptr;
-    int rc = AMDMSM_OK;
-    auto cleanup = [&]() {
-        if (d_src) (void)hipFree(d_src);
-        if (d_aff) (void)hipFree(d_aff);
-        if (d_sc) (void)hipFree(d_sc);
-        if (d_out) (void)hipFree(d_out);
-    };
-#define TRY_CLEAN(expr)                                                                              \
-    do {                                                                                             \
-        hipError_t e_ = (expr);                                                                      \
-        if (e_ != hipSuccess) {                                                                      \
-            cleanup();                                                                               \
-            return fail(ctx, AMDMSM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));     \
-        }                                                                                            \
-    } while (0)
-    TRY_CLEAN(hipMalloc(&d_out, xyz_bytes));
-    if (n) {
-        TRY_CLEAN(hipMalloc(&d_src, n * base_stride_bytes));
-        TRY_CLEAN(hipMalloc(&d_aff, n * aff_bytes));
-        TRY_CLEAN(hipMalloc(&d_sc, n * fr_bytes));
-        TRY_CLEAN(hipMemcpyAsync(d_src, bases_xyz, n * base_stride_bytes, hipMemcpyHostToDevice, st));
-        TRY_CLEAN(hipMemcpyAsync(d_sc, scalars, n * fr_bytes, hipMemcpyHostToDevice, st));
-        vt->import_bases(st, (const uint32_t *)d_src, base_stride_bytes / 4, base_form == AMDMSM_FORM_SPECIAL, n,
-                         (uint32_t *)d_aff);
+    int rc = ensure_buf(ctx, ctx->hb_out, xyz_bytes);
+    if (rc) return rc;
+    if (want_stats) {
+        rc = ensure_buf(ctx, ctx->hb_stats, 16);
+        if (rc) return rc;
+        HIP_TRY(ctx, hipMemsetAsync(ctx->hb_stats.p, 0, 16, st));
     }
     amdmsm_opts o = {};
     if (opts) o = *opts;
     else o.out_form = AMDMSM_OUT_LIBFF;
     o.stream = st;
-    rc = msm_device_impl(ctx, vt, (const uint32_t *)d_aff, (const uint32_t *)d_sc, n, (uint32_t *)d_out, &o);
-    if (rc == AMDMSM_OK) {
-        TRY_CLEAN(hipMemcpyAsync(out_xyz, d_out, xyz_bytes, hipMemcpyDeviceToHost, st));
-        TRY_CLEAN(hipStreamSynchronize(st));
+    void *d_aff = nullptr;
+    bases_upload up{ctx, vt, bases_xyz, stride, n, base_form};
+    msm_hook hook;
+    if (n) {
+        rc = ensure_buf(ctx, ctx->hb_sc, n * fr_bytes);
+        if (rc) return rc;
+        d_aff = find_resident_bases(ctx, vt, bases_xyz, stride, base_form, n);
+        if (!d_aff) d_aff = auto_cache_bases(ctx, vt, bases_xyz, stride, base_form, n);
+        if (!d_aff) {
+            rc = ensure_buf(ctx, ctx->hb_src, n * stride);
+            if (rc == AMDMSM_OK) rc = ensure_buf(ctx, ctx->hb_aff, n * aff_bytes);
+            if (rc) return rc;
+            d_aff = ctx->hb_aff.p;
+            hook.fn = upload_bases_hook;
+            hook.arg = &up;
+        }
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->hb_sc.p, scalars, n * fr_bytes, hipMemcpyHostToDevice, st));
+        if (want_stats) {
+            vt->scalar_stats(st, (const uint32_t *)ctx->hb_sc.p, n, o.scalars_plain ? 0 : 1, (uint32_t *)ctx->hb_stats.p);
+            HIP_TRY(ctx, hipGetLastError());
+        }
     }
-    cleanup();
-    return rc;
-#undef TRY_CLEAN
+    return msm_device_impl(ctx, vt, (const uint32_t *)d_aff, (const uint32_t *)ctx->hb_sc.p, n, (uint32_t *)ctx->hb_out.p, &o,
+                           0, &hook);
+}
+
+// one partial point from the device that produced it to the combining device (xGMI peer copy)
+hipError_t copy_partial(hipStream_t st, void *dst, int dst_dev, const void *src, int src_dev, size_t bytes) {
+    if (dst_dev == src_dev) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st);
+    return hipMemcpyPeerAsync(dst, dst_dev, src, src_dev, bytes, st);
+}
+
+int check_host_args(amdmsm_ctx *ctx, const group_vtable *vt, const void *bases_xyz, size_t &stride, const void *scalars,
+                    size_t n, const void *out_xyz) {
+    if (!out_xyz || (n && (!bases_xyz || !scalars))) return fail(ctx, AMDMSM_ERR_BAD_ARG, "null pointer");
+    const size_t xyz_bytes = (size_t)vt->el_words * 12;
+    if (stride == 0) stride = xyz_bytes;
+    if (stride % 16 || stride < xyz_bytes) return fail(ctx, AMDMSM_ERR_BAD_ARG, "base stride");
+    return AMDMSM_OK;
+}
+
+int host_multi_exp(amdmsm_ctx *ctx, const group_vtable *vt, const void *bases_xyz, size_t stride, int base_form,
+                   const void *scalars, size_t n, void *out_xyz, const amdmsm_opts *opts, size_t stats[3]) {
+    int rc = check_host_args(ctx, vt, bases_xyz, stride, scalars, n, out_xyz);
+    if (rc) return rc;
+    rc = host_msm_enqueue(ctx, vt, bases_xyz, stride, base_form, scalars, n, opts, stats != nullptr);
+    if (rc) {
+        (void)hipDeviceSynchronize();   // nothing of this call may still touch the staging buffers
+        return rc;
+    }
+    hipStream_t st = ctx->stream;
+    uint32_t hs[4] = {};
+    HIP_TRY(ctx, hipMemcpyAsync(out_xyz, ctx->hb_out.p, (size_t)vt->el_words * 12, hipMemcpyDeviceToHost, st));
+    if (stats) HIP_TRY(ctx, hipMemcpyAsync(hs, ctx->hb_stats.p, 16, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_stream));
+    if (stats) {
+        stats[0] = hs[0];
+        stats[1] = hs[1];
+        stats[2] = n - hs[0] - hs[1];
+    }
+    return AMDMSM_OK;
+}
+
+}   // namespace
+
+extern "C" {
+
+int amdmsm_multi_exp(amdmsm_ctx *ctx, int curve, int group, const void *bases_xyz, size_t base_stride_bytes,
+                     int base_form, const void *scalars, size_t n, void *out_xyz, const amdmsm_opts *opts) {
+    GET_VT(ctx, curve, group);
+    return host_multi_exp(ctx, vt, bases_xyz, base_stride_bytes, base_form, scalars, n, out_xyz, opts, nullptr);
 }
 
 int amdmsm_multi_exp_filter_one_zero(amdmsm_ctx *ctx, int curve, int group, const void *bases_xyz,
@@ -793,23 +1004,181 @@ int amdmsm_multi_exp_filter_one_zero(amdmsm_ctx *ctx, int curve, int group, cons
     // multiexp.tcc:690-757 separates scalars equal to 0 and 1 before the Pippenger
     // pass.  On the device a zero scalar recodes to all-zero digits (no work) and a
     // one lands in bucket 1 of window 0, so the same kernels compute the same sum;
-    // only the three statistics the reference prints need the classification.
-    if (stats) {
-        const group_vtable *vt = find_vt(curve, group);
-        if (!vt) return AMDMSM_ERR_UNSUPPORTED;
-        const size_t fr_bytes = (size_t)vt->fr_words * 4;
-        std::vector<unsigned char> zero(fr_bytes, 0), one(fr_bytes, 0);
-        if (opts && opts->scalars_plain) one[0] = 1;
-        else memcpy(one.data(), vt->fr_one_mont, fr_bytes);   // FieldT::one(), multiexp.tcc:723
-        stats[0] = stats[1] = stats[2] = 0;
-        for (size_t i = 0; i < n; ++i) {
-            const unsigned char *s = (const unsigned char *)scalars + i * fr_bytes;
-            if (memcmp(s, zero.data(), fr_bytes) == 0) ++stats[0];
-            else if (memcmp(s, one.data(), fr_bytes) == 0) ++stats[1];
-            else ++stats[2];
+    // only the three statistics the reference prints need the classification, which
+    // k_scalar_stats counts on the device from the scalars already in HBM.
+    GET_VT(ctx, curve, group);
+    return host_multi_exp(ctx, vt, bases_xyz, base_stride_bytes, base_form, scalars, n, out_xyz, opts, stats);
+}
+
+int amdmsm_register_bases(amdmsm_ctx *ctx, int curve, int group, const void *bases_xyz, size_t base_stride_bytes,
+                          int base_form, size_t n, uint64_t *handle) {
+    GET_VT(ctx, curve, group);
+    if (!bases_xyz || !n) return fail(ctx, AMDMSM_ERR_BAD_ARG, "null / empty base vector");
+    const size_t xyz_bytes = (size_t)vt->el_words * 12;
+    if (base_stride_bytes == 0) base_stride_bytes = xyz_bytes;
+    if (base_stride_bytes % 16 || base_stride_bytes < xyz_bytes) return fail(ctx, AMDMSM_ERR_BAD_ARG, "base stride");
+    // a re-registration of the same range replaces the old copy
+    for (size_t i = ctx->bases.size(); i-- > 0;) {
+        const base_entry &e = ctx->bases[i];
+        if (e.host == (const char *)bases_xyz && e.curve == curve && e.group == group) drop_entry(ctx, i);
+    }
+    return register_bases_impl(ctx, vt, bases_xyz, base_stride_bytes, base_form, n, false, handle);
+}
+
+int amdmsm_unregister_bases(amdmsm_ctx *ctx, uint64_t handle) {
+    if (!ctx) return AMDMSM_ERR_BAD_ARG;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    dev_guard g(ctx->device);
+    for (size_t i = 0; i < ctx->bases.size(); ++i) {
+        if (ctx->bases[i].id == handle) {
+            HIP_TRY(ctx, hipDeviceSynchronize());
+            drop_entry(ctx, i);
+            return AMDMSM_OK;
         }
     }
-    return amdmsm_multi_exp(ctx, curve, group, bases_xyz, base_stride_bytes, base_form, scalars, n, out_xyz, opts);
+    return fail(ctx, AMDMSM_ERR_BAD_ARG, "unknown base handle");
+}
+
+int amdmsm_invalidate_bases(amdmsm_ctx *ctx, const void *host_ptr, size_t bytes) {
+    if (!ctx) return AMDMSM_ERR_BAD_ARG;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    dev_guard g(ctx->device);
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    const char *lo = (const char *)host_ptr, *hi = lo + bytes;
+    for (size_t i = ctx->bases.size(); i-- > 0;) {
+        const base_entry &e = ctx->bases[i];
+        if (!host_ptr || (lo < e.host + e.n * e.stride && hi > e.host)) drop_entry(ctx, i);
+    }
+    return AMDMSM_OK;
+}
+
+// multi_exp across several devices of one node (multiexp.tcc:655-687 with chunk = device):
+// context k takes the contiguous range [k*one, (k+1)*one) (the last one the remainder), every
+// range runs the whole single-GPU pipeline on its own device from its own host thread, the
+// partial points are brought to the first device (hipMemcpyPeerAsync over xGMI) and summed there.
+int amdmsm_multi_exp_multi(amdmsm_ctx *const *ctxs, int ndev, int curve, int group, const void *bases_xyz,
+                           size_t base_stride_bytes, int base_form, const void *scalars, size_t n, void *out_xyz,
+                           const amdmsm_opts *opts) {
+    if (!ctxs || ndev < 1 || ndev > 64) return AMDMSM_ERR_BAD_ARG;
+    for (int k = 0; k < ndev; ++k) {
+        if (!ctxs[k]) return AMDMSM_ERR_BAD_ARG;
+        for (int j = 0; j < k; ++j) {
+            if (ctxs[j] == ctxs[k]) return fail(ctxs[0], AMDMSM_ERR_BAD_ARG, "the same context twice");
+        }
+    }
+    amdmsm_ctx *c0 = ctxs[0];
+    const group_vtable *vt = find_vt(curve, group);
+    if (!vt) return fail(c0, AMDMSM_ERR_UNSUPPORTED, "unknown curve/group");
+    if (ndev == 1 || n < (size_t)ndev) {
+        return amdmsm_multi_exp(c0, curve, group, bases_xyz, base_stride_bytes, base_form, scalars, n, out_xyz, opts);
+    }
+    // lock order = argument order; every caller passing the same list is deadlock-free
+    std::vector<std::unique_lock<std::recursive_mutex>> locks;
+    for (int k = 0; k < ndev; ++k) locks.emplace_back(ctxs[k]->mu);
+    size_t stride = base_stride_bytes;
+    int rc = check_host_args(c0, vt, bases_xyz, stride, scalars, n, out_xyz);
+    if (rc) return rc;
+    const size_t xyz_bytes = (size_t)vt->el_words * 12, fr_bytes = (size_t)vt->fr_words * 4;
+    const size_t one = n / (size_t)ndev;
+    amdmsm_opts o = {};
+    if (opts) o = *opts;
+    else o.out_form = AMDMSM_OUT_LIBFF;
+    const int final_form = o.out_form;
+    o.out_form = AMDMSM_OUT_JACOBIAN;
+    std::vector<int> rcs((size_t)ndev, AMDMSM_OK);
+    auto work = [&](int k) {
+        amdmsm_ctx *ctx = ctxs[k];
+        dev_guard g(ctx->device);
+        const size_t lo = (size_t)k * one, cnt = (k == ndev - 1) ? n - lo : one;
+        int r = host_msm_enqueue(ctx, vt, (const char *)bases_xyz + lo * stride, stride, base_form,
+                                 (const char *)scalars + lo * fr_bytes, cnt, &o, false);
+        if (r == AMDMSM_OK && hipEventRecord(ctx->host_done, ctx->stream) != hipSuccess) r = AMDMSM_ERR_HIP;
+        rcs[(size_t)k] = r;
+    };
+    std::vector<std::thread> threads;
+    for (int k = 1; k < ndev; ++k) threads.emplace_back(work, k);
+    work(0);
+    for (auto &t : threads) t.join();
+    for (int k = 0; k < ndev; ++k) {
+        if (rcs[(size_t)k]) rc = rcs[(size_t)k];
+    }
+    dev_guard g0(c0->device);
+    if (rc) {
+        for (int k = 0; k < ndev; ++k) {
+            dev_guard g(ctxs[k]->device);
+            (void)hipDeviceSynchronize();
+        }
+        if (rc && c0->err.empty()) c0->err = "a device range failed";
+        return rc;
+    }
+    if (!c0->chunk_partials) HIP_TRY(c0, hipMalloc(&c0->chunk_partials, 64 * 3 * 24 * 2 * 4));
+    hipStream_t st = c0->stream;
+    for (int k = 0; k < ndev; ++k) {
+        HIP_TRY(c0, hipStreamWaitEvent(st, ctxs[k]->host_done, 0));
+        HIP_TRY(c0, copy_partial(st, (char *)c0->chunk_partials + (size_t)k * xyz_bytes, c0->device, ctxs[k]->hb_out.p,
+                                 ctxs[k]->device, xyz_bytes));
+    }
+    vt->sum_points(st, (const uint32_t *)c0->chunk_partials, ndev, final_form, (uint32_t *)c0->hb_out.p);
+    HIP_TRY(c0, hipGetLastError());
+    HIP_TRY(c0, hipMemcpyAsync(out_xyz, c0->hb_out.p, xyz_bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c0, hipStreamSynchronize(st));
+    for (int k = 0; k < ndev; ++k) {
+        dev_guard g(ctxs[k]->device);
+        HIP_TRY(c0, hipStreamSynchronize(ctxs[k]->copy_stream));
+        HIP_TRY(c0, hipStreamSynchronize(ctxs[k]->stream));
+    }
+    return AMDMSM_OK;
+}
+
+// Device-resident counterpart: context k holds its own range (compact affine bases + scalars)
+// in its own HBM; partial k is reduced on device k and the partials are summed on device 0.
+int amdmsm_msm_device_multi(amdmsm_ctx *const *ctxs, int ndev, int curve, int group, const void *const *d_bases_affine,
+                            const void *const *d_scalars, const size_t *counts, void *d_out_xyz_dev0,
+                            const amdmsm_opts *opts) {
+    if (!ctxs || ndev < 1 || ndev > 64 || !d_bases_affine || !d_scalars || !counts || !d_out_xyz_dev0) return AMDMSM_ERR_BAD_ARG;
+    for (int k = 0; k < ndev; ++k) {
+        if (!ctxs[k]) return AMDMSM_ERR_BAD_ARG;
+        for (int j = 0; j < k; ++j) {
+            if (ctxs[j] == ctxs[k]) return fail(ctxs[0], AMDMSM_ERR_BAD_ARG, "the same context twice");
+        }
+    }
+    amdmsm_ctx *c0 = ctxs[0];
+    const group_vtable *vt = find_vt(curve, group);
+    if (!vt) return fail(c0, AMDMSM_ERR_UNSUPPORTED, "unknown curve/group");
+    std::vector<std::unique_lock<std::recursive_mutex>> locks;
+    for (int k = 0; k < ndev; ++k) locks.emplace_back(ctxs[k]->mu);
+    const size_t xyz_bytes = (size_t)vt->el_words * 12;
+    amdmsm_opts o = {};
+    if (opts) o = *opts;
+    else o.out_form = AMDMSM_OUT_LIBFF;
+    const int final_form = o.out_form;
+    hipStream_t user_stream = (hipStream_t)o.stream;   // ordering on device 0 only
+    o.out_form = AMDMSM_OUT_JACOBIAN;
+    o.stream = nullptr;
+    // kernels are asynchronous: one host thread enqueues all devices
+    for (int k = 0; k < ndev; ++k) {
+        amdmsm_ctx *ctx = ctxs[k];
+        dev_guard g(ctx->device);
+        int rc = ensure_buf(ctx, ctx->hb_out, xyz_bytes);
+        if (rc) return rc;
+        if (counts[k] && (!d_bases_affine[k] || !d_scalars[k])) return fail(c0, AMDMSM_ERR_BAD_ARG, "null pointer");
+        rc = msm_device_impl(ctx, vt, (const uint32_t *)d_bases_affine[k], (const uint32_t *)d_scalars[k], counts[k],
+                             (uint32_t *)ctx->hb_out.p, &o);
+        if (rc) return rc;
+        HIP_TRY(ctx, hipEventRecord(ctx->host_done, ctx->stream));
+    }
+    dev_guard g0(c0->device);
+    if (!c0->chunk_partials) HIP_TRY(c0, hipMalloc(&c0->chunk_partials, 64 * 3 * 24 * 2 * 4));
+    hipStream_t st = user_stream ? user_stream : c0->stream;
+    for (int k = 0; k < ndev; ++k) {
+        HIP_TRY(c0, hipStreamWaitEvent(st, ctxs[k]->host_done, 0));
+        HIP_TRY(c0, copy_partial(st, (char *)c0->chunk_partials + (size_t)k * xyz_bytes, c0->device, ctxs[k]->hb_out.p,
+                                 ctxs[k]->device, xyz_bytes));
+    }
+    vt->sum_points(st, (const uint32_t *)c0->chunk_partials, ndev, final_form, (uint32_t *)d_out_xyz_dev0);
+    HIP_TRY(c0, hipGetLastError());
+    HIP_TRY(c0, hipStreamSynchronize(st));   // the partials buffer is shared by the context
+    return AMDMSM_OK;
 }
 
 }   // extern "C"
@@ -841,11 +1210,9 @@ int stream_impl(amdmsm_ctx *ctx, int curve, int group, amdmsm_read_fn read, void
     hipStream_t streams[NB] = {};
     int rc = AMDMSM_OK;
     std::string err;
-    int old_depth = 1;
-    {
-        std::lock_guard<std::mutex> lock(ctx->mu);
-        old_depth = ctx->depth;
-    }
+    // the call owns the context from here on: it changes the pipeline depth and the slot rotation
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    const int old_depth = ctx->depth;
     dev_guard guard(ctx->device);
     auto cleanup = [&]() {
         (void)hipDeviceSynchronize();
@@ -913,11 +1280,8 @@ int stream_impl(amdmsm_ctx *ctx, int curve, int group, amdmsm_read_fn read, void
         }
     }
     TRY_S(hipDeviceSynchronize());
-    {
-        std::lock_guard<std::mutex> lock(ctx->mu);
-        vt->sum_points(ctx->stream, (const uint32_t *)d_partials, (int)nchunks, final_form,
-                       (uint32_t *)((char *)d_partials + nchunks * xyz_bytes));
-    }
+    vt->sum_points(ctx->stream, (const uint32_t *)d_partials, (int)nchunks, final_form,
+                   (uint32_t *)((char *)d_partials + nchunks * xyz_bytes));
     TRY_S(hipMemcpyAsync(out_xyz, (char *)d_partials + nchunks * xyz_bytes, xyz_bytes, hipMemcpyDeviceToHost, ctx->stream));
     TRY_S(hipStreamSynchronize(ctx->stream));
     cleanup();

@@ -18,23 +18,37 @@ std::mutex g_mu;
 amdmsm_ctx *g_ctx = nullptr;
 int g_device = 0;
 
-amdmsm_ctx *ffi_ctx() {
-    std::lock_guard<std::mutex> lock(g_mu);
+// device staging kept between calls (grow-only); guarded by g_mu like the context
+struct dev_buf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    bool reserve(size_t want) {
+        if (p && bytes >= want) return true;
+        if (p) {
+            (void)hipDeviceSynchronize();
+            (void)hipFree(p);
+            p = nullptr;
+            bytes = 0;
+        }
+        const size_t sz = want + want / 8 + 256;
+        if (hipMalloc(&p, sz) != hipSuccess) return false;
+        bytes = sz;
+        return true;
+    }
+};
+dev_buf g_in, g_aff, g_sc_in, g_sc, g_small;   // g_small: status word, result record, encoded result
+
+amdmsm_ctx *ffi_ctx_locked() {
     if (!g_ctx && amdmsm_ctx_create(g_device, &g_ctx) != AMDMSM_OK) g_ctx = nullptr;
     return g_ctx;
 }
 
-struct dev_buf {
-    void *p = nullptr;
-    ~dev_buf() {
-        if (p) (void)hipFree(p);
-    }
-    bool alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16) == hipSuccess; }
-};
-
-bool g1_multiexp(int curve, const void *bases, size_t bases_size, const void *scalars, size_t scalars_size,
-                 void *out, size_t out_size) {
-    const group_vtable *vt = amdmsm_internal_find_vt(curve, AMDMSM_G1);
+// <curve>_g{1,2}_multiexp: n = bases_size / (2 * coordinate bytes); G2 coordinates are Fq2
+// elements, c1 then c0 (field_element codec: highest-order coefficient first,
+// ffi_serialization.tcc:19-54), so a G2 element of bls12_377 is 4 x 48 = 192 bytes (ffi.h:13-17).
+bool ffi_multiexp(int curve, int group, const void *bases, size_t bases_size, const void *scalars, size_t scalars_size,
+                  void *out, size_t out_size) {
+    const group_vtable *vt = amdmsm_internal_find_vt(curve, group);
     if (!vt) return false;
     const size_t coord = (size_t)vt->el_words * 4, fr = (size_t)vt->fr_words * 4;
     // exact sizes, like object_read_from_buffer (ffi_serialization.tcc:98-104)
@@ -43,36 +57,42 @@ bool g1_multiexp(int curve, const void *bases, size_t bases_size, const void *sc
     const size_t n = bases_size / (2 * coord);
     if (scalars_size / fr != n) return false;
     if (n && (!bases || !scalars)) return false;
-    amdmsm_ctx *ctx = ffi_ctx();
-    if (!ctx) return false;
     std::lock_guard<std::mutex> lock(g_mu);   // one FFI call at a time on the shared context
-    if (hipSetDevice(g_device) != hipSuccess) return false;
+    amdmsm_ctx *ctx = ffi_ctx_locked();
+    if (!ctx) return false;
+    dev_guard guard(g_device);   // the caller's current device is restored on return
     hipStream_t st = (hipStream_t)amdmsm_internal_stream(ctx);
-    dev_buf d_in, d_aff, d_sc_in, d_sc, d_status, d_res, d_out;
-    if (!d_in.alloc(bases_size) || !d_aff.alloc(bases_size) || !d_sc_in.alloc(scalars_size) ||
-        !d_sc.alloc(scalars_size) || !d_status.alloc(4) || !d_res.alloc(3 * coord) || !d_out.alloc(2 * coord)) {
+    const size_t small_bytes = 256 + 5 * coord;
+    if (!g_in.reserve(bases_size) || !g_aff.reserve(bases_size) || !g_sc_in.reserve(scalars_size) ||
+        !g_sc.reserve(scalars_size) || !g_small.reserve(small_bytes)) {
         return false;
     }
-    if (hipMemsetAsync(d_status.p, 0, 4, st) != hipSuccess) return false;
+    char *d_status = (char *)g_small.p, *d_res = d_status + 256, *d_out = d_res + 3 * coord;
+    if (hipMemsetAsync(d_status, 0, 4, st) != hipSuccess) return false;
     if (n) {
-        if (hipMemcpyAsync(d_in.p, bases, bases_size, hipMemcpyHostToDevice, st) != hipSuccess) return false;
-        if (hipMemcpyAsync(d_sc_in.p, scalars, scalars_size, hipMemcpyHostToDevice, st) != hipSuccess) return false;
-        vt->ffi_decode_points(st, (const uint32_t *)d_in.p, n, (uint32_t *)d_aff.p, (uint32_t *)d_status.p);
-        vt->ffi_decode_scalars(st, (const uint32_t *)d_sc_in.p, n, (uint32_t *)d_sc.p, (uint32_t *)d_status.p);
+        if (hipMemcpyAsync(g_in.p, bases, bases_size, hipMemcpyHostToDevice, st) != hipSuccess) return false;
+        if (hipMemcpyAsync(g_sc_in.p, scalars, scalars_size, hipMemcpyHostToDevice, st) != hipSuccess) return false;
+        vt->ffi_decode_points(st, (const uint32_t *)g_in.p, n, (uint32_t *)g_aff.p, (uint32_t *)d_status);
+        vt->ffi_decode_scalars(st, (const uint32_t *)g_sc_in.p, n, (uint32_t *)g_sc.p, (uint32_t *)d_status);
     }
-    unsigned status = 0;
-    if (hipMemcpyAsync(&status, d_status.p, 4, hipMemcpyDeviceToHost, st) != hipSuccess) return false;
-    if (hipStreamSynchronize(st) != hipSuccess || status != 0) return false;
+    // The MSM is enqueued behind the validation without waiting for its verdict (one
+    // synchronisation per call); a rejected input costs a wasted MSM, an accepted one nothing.
     amdmsm_opts o = {};
     o.out_form = AMDMSM_OUT_AFFINE;
     o.scalars_plain = 1;
     o.stream = st;
-    if (amdmsm_msm_device(ctx, curve, AMDMSM_G1, d_aff.p, d_sc.p, n, d_res.p, &o) != AMDMSM_OK) return false;
-    vt->ffi_encode_point(st, (const uint32_t *)d_res.p, (uint32_t *)d_out.p);
-    unsigned char tmp[2 * 96];
-    if (hipMemcpyAsync(tmp, d_out.p, 2 * coord, hipMemcpyDeviceToHost, st) != hipSuccess) return false;
-    if (hipStreamSynchronize(st) != hipSuccess) return false;
-    memcpy(out, tmp, 2 * coord);
+    if (amdmsm_msm_device(ctx, curve, group, g_aff.p, g_sc.p, n, d_res, &o) != AMDMSM_OK) {
+        (void)hipStreamSynchronize(st);
+        return false;
+    }
+    vt->ffi_encode_point(st, (const uint32_t *)d_res, (uint32_t *)d_out);
+    unsigned status = 0;
+    unsigned char tmp[2 * 2 * 96];   // largest element: bw6_761 G1/G2 or bls12_377 G2, 192 bytes
+    if (2 * coord > sizeof(tmp)) return false;
+    if (hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, st) != hipSuccess) return false;
+    if (hipMemcpyAsync(tmp, d_out, 2 * coord, hipMemcpyDeviceToHost, st) != hipSuccess) return false;
+    if (hipStreamSynchronize(st) != hipSuccess || status != 0) return false;
+    memcpy(out, tmp, 2 * coord);   // output untouched on every failure path above
     return true;
 }
 
@@ -88,19 +108,17 @@ bool amdmsm_ffi_set_device(int device) {
     return true;
 }
 
-bool alt_bn128_g1_multiexp(const void *bases_g1, size_t bases_g1_size, const void *scalars_fr, size_t scalars_fr_size,
-                           void *out_g1, size_t out_g1_size) {
-    return g1_multiexp(AMDMSM_CURVE_ALT_BN128, bases_g1, bases_g1_size, scalars_fr, scalars_fr_size, out_g1, out_g1_size);
-}
+#define AMDMSM_FFI_MULTIEXP(NAME, CURVE, GROUP)                                                                       \
+    bool NAME(const void *bases, size_t bases_size, const void *scalars_fr, size_t scalars_fr_size, void *out,       \
+              size_t out_size) {                                                                                      \
+        return ffi_multiexp(CURVE, GROUP, bases, bases_size, scalars_fr, scalars_fr_size, out, out_size);             \
+    }
 
-bool bls12_377_g1_multiexp(const void *bases_g1, size_t bases_g1_size, const void *scalars_fr, size_t scalars_fr_size,
-                           void *out_g1, size_t out_g1_size) {
-    return g1_multiexp(AMDMSM_CURVE_BLS12_377, bases_g1, bases_g1_size, scalars_fr, scalars_fr_size, out_g1, out_g1_size);
-}
-
-bool bw6_761_g1_multiexp(const void *bases_g1, size_t bases_g1_size, const void *scalars_fr, size_t scalars_fr_size,
-                         void *out_g1, size_t out_g1_size) {
-    return g1_multiexp(AMDMSM_CURVE_BW6_761, bases_g1, bases_g1_size, scalars_fr, scalars_fr_size, out_g1, out_g1_size);
-}
+AMDMSM_FFI_MULTIEXP(alt_bn128_g1_multiexp, AMDMSM_CURVE_ALT_BN128, AMDMSM_G1)
+AMDMSM_FFI_MULTIEXP(alt_bn128_g2_multiexp, AMDMSM_CURVE_ALT_BN128, AMDMSM_G2)
+AMDMSM_FFI_MULTIEXP(bls12_377_g1_multiexp, AMDMSM_CURVE_BLS12_377, AMDMSM_G1)
+AMDMSM_FFI_MULTIEXP(bls12_377_g2_multiexp, AMDMSM_CURVE_BLS12_377, AMDMSM_G2)
+AMDMSM_FFI_MULTIEXP(bw6_761_g1_multiexp, AMDMSM_CURVE_BW6_761, AMDMSM_G1)
+AMDMSM_FFI_MULTIEXP(bw6_761_g2_multiexp, AMDMSM_CURVE_BW6_761, AMDMSM_G2)
 
 }  // extern "C"

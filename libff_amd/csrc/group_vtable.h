@@ -68,6 +68,9 @@ struct group_vtable {
     // cursor[] holds exclusive bucket starts on entry, bucket ends on exit
     void (*scatter)(hipStream_t, const uint32_t* scalars, size_t n, int mont, int c, int W, uint32_t* cursor,
                     uint32_t* lists, size_t list_stride);
+    // stats[0] += #scalars equal to zero, stats[1] += #scalars equal to one (multi_exp_filter_one_zero's
+    // classification, multiexp.tcc:713-733); mont: the scalars are Montgomery residues
+    void (*scalar_stats)(hipStream_t, const uint32_t* scalars, size_t n, int mont, uint32_t* stats);
     // LDS-staged two-level sort (same result as count + scatter): ends[w][b] and lists[w][...].
     // coarse: W*(2^hb+1) words zeroed, cursor: W*2^hb words, digits/tmp_payload/tmp_key/lists:
     // W*stride words each (digits may alias lists); big: sort_geometry().big_words words, the

@@ -27,6 +27,7 @@
 #include "group_vtable.h"
 #include "wide.cuh"
 
+#include <algorithm>
 #include <type_traits>
 
 #ifndef AMDMSM_GROUP
@@ -269,6 +270,34 @@ __global__ void __launch_bounds__(TPB) k_digits(const uint32_t* __restrict__ sca
     uint32_t s[FRW];
     load_scalar(s, scalars, i, mont);
     for_each_signed_digit(s, c, W, [&](int w, int32_t d) { out[i * (size_t)W + w] = d; });
+}
+
+// multi_exp_filter_one_zero's classification (multiexp.tcc:713-733: is_zero(), == FieldT::one())
+// as two device counters; one global atomic per wave and class.
+__global__ void __launch_bounds__(TPB) k_scalar_stats(const uint32_t* __restrict__ scalars, size_t n, int mont,
+                                                      uint32_t* __restrict__ stats) {
+    uint32_t zeros = 0, ones = 0;
+    for (size_t i = gtid(); i < n; i += (size_t)gridDim.x * TPB) {
+        Fp<FR> x, one;
+        fp_load(x, scalars + i * FRW);
+        if (mont) {
+            fp_set_one(one);
+        } else {
+            fp_set_zero(one);
+            one.v[0] = 1u;
+        }
+        zeros += fp_is_zero(x) ? 1u : 0u;
+        ones += fp_eq(x, one) ? 1u : 0u;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        zeros += (uint32_t)__shfl_xor((int)zeros, off, 64);
+        ones += (uint32_t)__shfl_xor((int)ones, off, 64);
+    }
+    if ((threadIdx.x & 63u) == 0) {
+        if (zeros) atomicAdd(&stats[0], zeros);
+        if (ones) atomicAdd(&stats[1], ones);
+    }
 }
 
 // Exclusive scan of one window's histogram per workgroup (grid.x = W).
@@ -1624,6 +1653,11 @@ void l_count(hipStream_t st, const uint32_t* scalars, size_t n, int mont, int c,
     hipLaunchKernelGGL(k_count, dim3(blocks_for(n)), dim3(TPB), 0, st, scalars, n, mont, c, W, counts);
     hipLaunchKernelGGL(k_scan, dim3(W), dim3(SCAN_TPB), 0, st, counts, (uint32_t)1 << (c - 1));
 }
+void l_scalar_stats(hipStream_t st, const uint32_t* scalars, size_t n, int mont, uint32_t* stats) {
+    if (!n) return;
+    const unsigned blocks = (unsigned)std::min<size_t>((n + TPB - 1) / TPB, 4096);
+    hipLaunchKernelGGL(k_scalar_stats, dim3(blocks), dim3(TPB), 0, st, scalars, n, mont, stats);
+}
 void l_scatter(hipStream_t st, const uint32_t* scalars, size_t n, int mont, int c, int W, uint32_t* cursor,
                uint32_t* lists, size_t list_stride) {
     if (!n) return;
@@ -1644,7 +1678,7 @@ void l_sort(hipStream_t st, const uint32_t* scalars, size_t n, int mont, int c, 
     uint32_t per_block = 8192;
     while (per_block > SORT_TPB && (n + per_block - 1) / per_block < 1024) per_block >>= 1;
     hipLaunchKernelGGL(k_sort_digits, dim3((unsigned)((n + per_block - 1) / per_block)), dim3(SORT_TPB),
-                       (size_t)W * nbin * 4, st, scalars, n, mont, c, W, hb, per_block, digits, stride, coarse, flat);
+                       (size_t)(flat ? 1 : W) * nbin * 4, st, scalars, n, mont, c, W, hb, per_block, digits, stride, coarse, flat);
     hipLaunchKernelGGL(k_sort_scan, dim3(We), dim3(SORT_TPB), 0, st, coarse, cursor, nbin);
     hipLaunchKernelGGL(k_sort_coarse, dim3((unsigned)((ne + SORT_TILE - 1) / SORT_TILE), We), dim3(SORT_TPB), 0, st, digits,
                        ne, stride, c, hb, cursor, tmp_payload, tmp_key);
@@ -1780,7 +1814,7 @@ void l_madd_bench(hipStream_t st, const uint32_t* pts, uint32_t* out, size_t nth
 
 const group_vtable g_vt = {
     GP::CURVE, GP::GROUP, FRW, EW, FQ::N, FR::BITS, GP::LIBFF_PROJECTIVE ? 1 : 0, FR::R,
-    l_import_bases, l_precompute_table, l_count, l_scatter, l_sort, l_accumulate, l_accumulate_resident_lanes, l_accumulate_fixup, l_reduce_segments, l_sum_butterfly, l_horner, l_sum_points,
+    l_import_bases, l_precompute_table, l_count, l_scatter, l_scalar_stats, l_sort, l_accumulate, l_accumulate_resident_lanes, l_accumulate_fixup, l_reduce_segments, l_sum_butterfly, l_horner, l_sum_points,
     l_gen_bases_seq, l_export_affine, l_ffi_decode_points, l_ffi_decode_scalars, l_ffi_encode_point, l_disk_decode, l_fixed_base_exp, l_field_op, l_group_op, l_digits, l_mul_bench, l_madd_bench,
 };
 

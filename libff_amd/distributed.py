@@ -67,14 +67,20 @@ class ShardedMsm:
         words = self.sz["g_bytes"] // 8
         self.partial = [torch.zeros(words, dtype=torch.int64, device=dev) for _ in range(depth)]
         self.result = [torch.zeros(words, dtype=torch.int64, device=dev) for _ in range(depth)]
-        self.streams = [torch.cuda.current_stream(dev)] if depth == 1 else [torch.cuda.Stream(dev) for _ in range(depth)]
+        # Always explicit, non-default streams: torch's default stream has handle 0, which the C ABI
+        # reads as "the context's own stream" -- a non-blocking stream that does not synchronise
+        # with torch's legacy null stream, so the all-gather (ordered by torch's current stream)
+        # could read the partial before the MSM has written it.
+        self.streams = [torch.cuda.Stream(dev) for _ in range(depth)]
         self.k = 0
         engine.set_pipeline_depth(depth)
 
     def run(self, bases_affine, scalars, n, out_form, window_bits=0):
         """bases_affine / scalars: this rank's shard (torch tensors on its GPU).  Returns
-        (result tensor, workspace slot); with depth > 1 the result is ready once the step's
-        stream has been synchronised (``synchronize()``)."""
+        (result tensor, workspace slot).  The MSM, the all-gather (RCCL orders itself on torch's
+        current stream, which is the step's stream inside the ``with`` block) and the final sum all
+        run on the step's own stream; the result is ready once that stream has been synchronised
+        (``synchronize()``) or waited for (``streams[slot]``)."""
         from .engine import OUT_JACOBIAN
         import torch.distributed as dist
 
@@ -82,7 +88,10 @@ class ShardedMsm:
         i = self.k % self.depth
         self.k += 1
         stream = self.streams[i]
+        assert stream.cuda_stream != 0
         partial, result = self.partial[i], self.result[i]
+        # inputs were produced on the caller's current stream
+        stream.wait_stream(torch.cuda.current_stream(stream.device))
         with torch.cuda.stream(stream):
             self.engine.msm_device(self.curve, self.group_id, bases_affine.data_ptr(), scalars.data_ptr(), n,
                                    partial.data_ptr(), out_form=OUT_JACOBIAN, window_bits=window_bits,

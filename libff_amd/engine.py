@@ -42,6 +42,8 @@ EXPORTED_SYMBOLS = [
     "amdmsm_device_count", "amdmsm_ctx_create", "amdmsm_ctx_destroy", "amdmsm_strerror",
     "amdmsm_last_error", "amdmsm_sizes", "amdmsm_plan", "amdmsm_pippenger_optimal_c",
     "amdmsm_bdlo12_signed_optimal_c", "amdmsm_multi_exp", "amdmsm_multi_exp_filter_one_zero",
+    "amdmsm_multi_exp_multi", "amdmsm_msm_device_multi", "amdmsm_register_bases", "amdmsm_unregister_bases",
+    "amdmsm_invalidate_bases",
     "amdmsm_batch_to_special", "amdmsm_batch_exp", "amdmsm_multi_exp_stream", "amdmsm_multi_exp_stream_file",
     "amdmsm_precompute_num_digits", "amdmsm_multi_exp_stream_with_precompute",
     "amdmsm_multi_exp_stream_with_precompute_file", "amdmsm_precompute_bases_device",
@@ -122,6 +124,40 @@ def plan(curve, group, n, window_bits=0):
     return {"c": c.value, "num_windows": w.value, "num_buckets": b.value, "workspace_bytes": ws.value}
 
 
+def multi_exp_multi(engines, curve, group, bases, scalars, base_form=multi_exp_base_form_normal,
+                    out_form=OUT_AFFINE, window_bits=0, scalars_plain=False):
+    """amdmsm_multi_exp_multi: libff's range split (multiexp.tcc:655-687) with chunk = engine context
+    (one per GPU, or several on one GPU), partials combined on engines[0]'s device."""
+    bases = np.ascontiguousarray(bases, dtype=np.uint64)
+    scalars = np.ascontiguousarray(scalars, dtype=np.uint64)
+    s = sizes(curve, group)
+    n = bases.shape[0] if bases.ndim == 2 else 0
+    out = np.zeros(s["g_bytes"] // 8, dtype=np.uint64)
+    e0 = engines[0]
+    ctxs = (ctypes.c_void_p * len(engines))(*[e.h for e in engines])
+    o = e0._opts(window_bits=window_bits, out_form=out_form, scalars_plain=scalars_plain)
+    rc = e0.lib.amdmsm_multi_exp_multi(ctxs, len(engines), curve, group, _np_ptr(bases) if n else None,
+                                       ctypes.c_size_t(s["g_bytes"]), base_form, _np_ptr(scalars) if n else None,
+                                       ctypes.c_size_t(n), _np_ptr(out), ctypes.byref(o))
+    e0._check(rc, "amdmsm_multi_exp_multi")
+    return out
+
+
+def msm_device_multi(engines, curve, group, d_bases, d_scalars, counts, d_out_dev0, out_form=OUT_LIBFF, window_bits=0,
+                     scalars_plain=False, stream=None):
+    """amdmsm_msm_device_multi: range k (compact affine bases, scalars; device pointers on
+    engines[k]'s GPU) is reduced there, the partials are summed on engines[0]'s GPU into d_out_dev0."""
+    k = len(engines)
+    e0 = engines[0]
+    ctxs = (ctypes.c_void_p * k)(*[e.h for e in engines])
+    pb = (ctypes.c_void_p * k)(*[_vp(x) for x in d_bases])
+    ps = (ctypes.c_void_p * k)(*[_vp(x) for x in d_scalars])
+    cn = (ctypes.c_size_t * k)(*counts)
+    o = e0._opts(window_bits=window_bits, out_form=out_form, scalars_plain=scalars_plain, stream=stream)
+    rc = e0.lib.amdmsm_msm_device_multi(ctxs, k, curve, group, pb, ps, cn, _vp(d_out_dev0), ctypes.byref(o))
+    e0._check(rc, "amdmsm_msm_device_multi")
+
+
 def _vp(x):
     """device address (int, e.g. torch's data_ptr()) or c_void_p (Engine.malloc) -> c_void_p"""
     return x if isinstance(x, ctypes.c_void_p) else ctypes.c_void_p(x)
@@ -166,13 +202,17 @@ class Engine:
     # ---------------------------------------------------------------- host API
     def multi_exp(self, curve, group, bases, scalars, method=multi_exp_method_BDLO12_signed,
                   base_form=multi_exp_base_form_normal, chunks=1, out_form=OUT_AFFINE, window_bits=0,
-                  scalars_plain=False):
+                  scalars_plain=False, split_chunks=False):
         """libff::multi_exp<G, Fr, Method, BaseForm>(bases, scalars, chunks), multiexp.tcc:643-688.
 
         BDLO12 and BDLO12_signed both run the device Pippenger engine (the result is a
-        group element; it does not depend on the digit convention).  ``chunks`` > 1 takes
-        the reference's split-and-sum route: contiguous ranges (last one takes the
-        remainder), one partial per range, partials summed on the device.
+        group element; it does not depend on the digit convention).  ``chunks`` is the
+        reference's CPU-thread hint (libsnark passes its OpenMP thread count): one GPU runs the
+        whole input as ONE MSM whatever its value -- splitting would only multiply the fixed
+        costs -- and across GPUs the split is ``multi_exp_multi``'s.  ``split_chunks=True``
+        forces the reference's split-and-sum shape (contiguous ranges, the last one takes the
+        remainder, partials summed; multiexp.tcc:655-687) on this one device, for the parity tests
+        of range sharding.
         """
         if method not in (multi_exp_method_BDLO12, multi_exp_method_BDLO12_signed):
             raise NotImplementedError("only the BDLO12 / BDLO12_signed methods run on the GPU engine")
@@ -185,7 +225,7 @@ class Engine:
             assert scalars.shape == (n, s["fr_bytes"] // 8), "scalars must be (n, fr_limbs) uint64"
         out = np.zeros(s["g_bytes"] // 8, dtype=np.uint64)
         total = n
-        if total < chunks or chunks == 1:
+        if total < chunks or chunks == 1 or not split_chunks:
             o = self._opts(window_bits=window_bits, out_form=out_form, scalars_plain=scalars_plain)
             rc = self.lib.amdmsm_multi_exp(self.h, curve, group, _np_ptr(bases) if n else None,
                                            ctypes.c_size_t(s["g_bytes"]), base_form,
@@ -205,6 +245,26 @@ class Engine:
                                            _np_ptr(partials[i]), ctypes.byref(o))
             self._check(rc, "amdmsm_multi_exp")
         return self.sum_points(curve, group, partials, out_form=out_form)
+
+    def register_bases(self, curve, group, bases, base_form=multi_exp_base_form_normal):
+        """amdmsm_register_bases: keep ``bases`` (the very numpy buffer -- the registry is keyed on its
+        address) resident in HBM; later host-buffer calls on it or on row ranges of it skip the base
+        transfer and import.  Returns a handle for ``unregister_bases``."""
+        assert bases.dtype == np.uint64 and bases.flags["C_CONTIGUOUS"]
+        s = sizes(curve, group)
+        h = ctypes.c_uint64(0)
+        rc = self.lib.amdmsm_register_bases(self.h, curve, group, _np_ptr(bases), ctypes.c_size_t(s["g_bytes"]),
+                                            base_form, ctypes.c_size_t(bases.shape[0]), ctypes.byref(h))
+        self._check(rc, "amdmsm_register_bases")
+        return h.value
+
+    def unregister_bases(self, handle):
+        self._check(self.lib.amdmsm_unregister_bases(self.h, ctypes.c_uint64(handle)), "amdmsm_unregister_bases")
+
+    def invalidate_bases(self, arr=None):
+        rc = self.lib.amdmsm_invalidate_bases(self.h, _np_ptr(arr) if arr is not None else None,
+                                              ctypes.c_size_t(arr.nbytes if arr is not None else 0))
+        self._check(rc, "amdmsm_invalidate_bases")
 
     def multi_exp_filter_one_zero(self, curve, group, bases, scalars, method=multi_exp_method_BDLO12_signed,
                                   base_form=multi_exp_base_form_normal, chunks=1, out_form=OUT_AFFINE,

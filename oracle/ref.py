@@ -193,6 +193,42 @@ def disk_write(curve, group, elems):
     return out
 
 
+def disk_write_compressed(curve, group, elems):
+    """group_write<encoding_binary, form_montgomery, compression_on> records (curve_serialization.tcc:110-133)."""
+    s = sizes(curve, group)
+    elems = np.ascontiguousarray(elems, dtype=np.uint64)
+    n = elems.shape[0]
+    out = np.zeros(n * s["coord_bytes"], dtype=np.uint8)
+    lib().ref_disk_write_compressed.restype = ctypes.c_size_t
+    got = lib().ref_disk_write_compressed(curve, group, ctypes.c_size_t(n), _p(elems), _p(out), ctypes.c_size_t(out.size))
+    assert got == out.size, (got, out.size)
+    return out
+
+
+def disk_read_compressed(curve, group, data, n):
+    """group_read<encoding_binary, form_montgomery, compression_on> (curve_serialization.tcc:134-166)."""
+    s = sizes(curve, group)
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    out = np.zeros((n, s["g_bytes"] // 8), dtype=np.uint64)
+    assert lib().ref_disk_read_compressed(curve, group, ctypes.c_size_t(n), _p(data), ctypes.c_size_t(data.size), _p(out)) == 0
+    return out
+
+
+def curve_points(curve, group, seed, n):
+    """n points of the curve found by scanning x upwards from ``seed`` (curve_point_y_at_x), with the
+    reference's own verdicts: flags & 1 = is_well_formed(), flags & 2 = is_in_safe_subgroup()."""
+    s = sizes(curve, group)
+    out = np.zeros((n, s["g_bytes"] // 8), dtype=np.uint64)
+    flags = np.zeros(n, dtype=np.int32)
+    assert lib().ref_curve_points(curve, group, ctypes.c_uint64(seed), ctypes.c_size_t(n), _p(out), _p(flags)) == 0
+    return out, flags
+
+
+def point_checks(curve, group, pt):
+    pt = np.ascontiguousarray(pt, dtype=np.uint64)
+    return int(lib().ref_point_checks(curve, group, _p(pt)))
+
+
 def precompute_table(curve, group, bases, c, num_digits):
     bases = np.ascontiguousarray(bases, dtype=np.uint64)
     n = bases.shape[0]

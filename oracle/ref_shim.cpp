@@ -270,6 +270,71 @@ template<typename G, typename Fr> struct ops {
         memcpy(out, s.data(), s.size());
         return s.size();
     }
+    // group_write / group_read<encoding_binary, form_montgomery, compression_on>
+    // (curve_serialization.tcc:110-166): X with two flag bits, Y recovered by sqrt on read
+    static size_t disk_write_compressed(size_t n, const void *elems, void *out, size_t cap)
+    {
+        std::ostringstream os(std::ios_base::out | std::ios_base::binary);
+        const G *e = (const G *)elems;
+        for (size_t i = 0; i < n; ++i) {
+            G tmp;
+            memcpy((void *)&tmp, (const void *)&e[i], sizeof(G));
+            group_write<encoding_binary, form_montgomery, compression_on>(tmp, os);
+        }
+        const std::string s = os.str();
+        if (s.size() > cap) return 0;
+        memcpy(out, s.data(), s.size());
+        return s.size();
+    }
+    static int disk_read_compressed(size_t n, const void *bytes, size_t nbytes, void *out)
+    {
+        std::istringstream is(std::string((const char *)bytes, nbytes), std::ios_base::in | std::ios_base::binary);
+        G *o = (G *)out;
+        for (size_t i = 0; i < n; ++i) {
+            G tmp;
+            group_read<encoding_binary, form_montgomery, compression_on>(tmp, is);
+            memcpy((void *)&o[i], (const void *)&tmp, sizeof(G));
+        }
+        return 0;
+    }
+
+    // x = seed, seed + 1, ... (Fq2: (seed + k) + 1*u) until n of them lie on the curve
+    // (curve_point_y_at_x, curve_utils.tcc:34-47, behind the Euler test of :49-64); out: affine
+    // records; flags[i] = is_well_formed() | is_in_safe_subgroup() << 1 as the reference answers
+    template<mp_size_t n_, const bigint<n_> &m_>
+    static Fp_model<n_, m_> make_x(const Fp_model<n_, m_> *, uint64_t s)
+    {
+        return Fp_model<n_, m_>((unsigned long)s);
+    }
+    template<mp_size_t n_, const bigint<n_> &m_>
+    static Fp2_model<n_, m_> make_x(const Fp2_model<n_, m_> *, uint64_t s)
+    {
+        return Fp2_model<n_, m_>(Fp_model<n_, m_>((unsigned long)s), Fp_model<n_, m_>::one());
+    }
+    static int curve_points(uint64_t seed, size_t n, void *out, int *flags)
+    {
+        G *o = (G *)out;
+        size_t found = 0;
+        for (uint64_t k = 0; found < n && k < 100000; ++k) {
+            const Fq x = make_x((const Fq *)nullptr, seed + k);
+            const Fq y2 = x * x * x + G::coeff_b;
+            if ((y2 ^ Fq::euler) != Fq::one()) {
+                continue;
+            }
+            const G p(x, y2.sqrt(), Fq::one());
+            flags[found] = (p.is_well_formed() ? 1 : 0) | (p.is_in_safe_subgroup() ? 2 : 0);
+            memcpy((void *)&o[found], (const void *)&p, sizeof(G));
+            ++found;
+        }
+        return found == n ? 0 : -1;
+    }
+    static int point_checks(const void *pt)
+    {
+        G p;
+        memcpy((void *)&p, pt, sizeof(G));
+        return (p.is_well_formed() ? 1 : 0) | (p.is_in_safe_subgroup() ? 2 : 0);
+    }
+
     static int stream_c(size_t n, const void *bytes, size_t nbytes, const void *scalars, void *out_affine)
     {
         std::istringstream is(std::string((const char *)bytes, nbytes), std::ios_base::in | std::ios_base::binary);
@@ -536,6 +601,34 @@ size_t ref_disk_write(int curve, int group, size_t n, const void *elems, void *o
     size_t r = 0;
     DISPATCH(curve, group, r = O::disk_write(n, elems, out, cap));
     return r;
+}
+
+size_t ref_disk_write_compressed(int curve, int group, size_t n, const void *elems, void *out, size_t cap)
+{
+    size_t r = 0;
+    DISPATCH(curve, group, r = O::disk_write_compressed(n, elems, out, cap));
+    return r;
+}
+
+int ref_disk_read_compressed(int curve, int group, size_t n, const void *bytes, size_t nbytes, void *out)
+{
+    int rc = 0;
+    DISPATCH(curve, group, rc = O::disk_read_compressed(n, bytes, nbytes, out));
+    return rc;
+}
+
+int ref_curve_points(int curve, int group, uint64_t seed, size_t n, void *out, int *flags)
+{
+    int rc = 0;
+    DISPATCH(curve, group, rc = O::curve_points(seed, n, out, flags));
+    return rc;
+}
+
+int ref_point_checks(int curve, int group, const void *pt)
+{
+    int rc = 0;
+    DISPATCH(curve, group, rc = O::point_checks(pt));
+    return rc;
 }
 
 int ref_multi_exp_stream(

@@ -89,3 +89,21 @@ def test_shard_range_matches_libff_chunking():
                 lo, hi = shard_range(total, world, r)
                 assert lo == r * one
                 assert hi == (total if r == world - 1 else (r + 1) * one)
+
+
+def test_bench_self_launch_propagates_child_failure():
+    """`python bench.py --gpus 2` with no launcher around it starts its two ranks itself
+    (torch.distributed.run children; the parent never touches a GPU).  On this GPU-less host
+    both ranks stop with the "needs an MI355X" message and the parent must exit non-zero."""
+    import subprocess
+    import sys
+
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible: the ranks would run the benchmark")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0
+    assert "needs an MI355X" in (r.stdout + r.stderr)

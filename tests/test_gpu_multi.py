@@ -1,0 +1,279 @@
+"""-m gpu: the multi-GPU shapes of BASELINE configs[3] / configs[4] and the boundary features
+around them, on the one GPU a test box has.
+
+  * per-rank shard sizes: alt_bn128 G1 2^23 (2^26 over 8 GPUs), bls12_377 G1 2^22 (configs[2]),
+    bw6_761 G1 2^21 and bls12_377 G2 2^21 issued together (2^24 over 8 GPUs) -- closed form
+    (the reference's own test pattern, test_multiexp.cpp:205-256) and sharded == unsharded;
+  * the C-ABI multi-device entries (amdmsm_multi_exp_multi / amdmsm_msm_device_multi,
+    multiexp.tcc:655-687 with chunk = context) with ndev = 1 and with two contexts on one device;
+  * ShardedMsm (the torch.distributed layer bench.py uses) through the nccl backend at world
+    size 1, with inputs that change every step;
+  * resident base vectors (amdmsm_register_bases) and the device-side filter_one_zero counts.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import libff_amd
+from common import golden, small_scalars_mont, to_int
+from libff_amd import multi_exp_base_form_normal, multi_exp_base_form_special
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _closed_form_point(port, curve, group, scalars_mont, first):
+    """(sum_i s_i * (first + i + 1) mod r) * G::one(), affine -- test_multiexp.cpp:205-256."""
+    plain = port.fr_as_bigint(curve, scalars_mont)
+    n, fl = plain.shape
+    r = to_int(golden()[f"{libff_amd.engine.CURVE_NAMES[curve]}_g1/fr_modulus"])
+    lo32 = (plain & np.uint64(0xFFFFFFFF)).astype(np.uint64)
+    hi32 = (plain >> np.uint64(32)).astype(np.uint64)
+    total = 0
+    blk = 256   # 2^32 * 2^24 * 2^8 = 2^64 would wrap: weights stay below 2^24 + blk here
+    for b0 in range(0, n, blk):
+        w = np.arange(first + b0 + 1, first + min(b0 + blk, n) + 1, dtype=np.uint64)[:, None]
+        lo = (lo32[b0:b0 + blk] * w).sum(axis=0, dtype=np.uint64)
+        hi = (hi32[b0:b0 + blk] * w).sum(axis=0, dtype=np.uint64)
+        for j in range(fl):
+            total += (int(lo[j]) << (64 * j)) + (int(hi[j]) << (64 * j + 32))
+    k = total % r
+    k_plain = np.array([[(k >> (64 * j)) & 0xFFFFFFFFFFFFFFFF for j in range(fl)]], dtype=np.uint64)
+    k_mont = port.fr_from_bigint(curve, k_plain)[0]
+    one, _ = port.group_consts(curve, group)
+    return port.group_op(curve, group, 4, port.scalar_mul(curve, group, one, k_mont))
+
+
+class _Resident:
+    """(first + i + 1) * G bases generated in HBM + uploaded scalars, for one engine context."""
+
+    def __init__(self, eng, curve, group, n, first, scalars):
+        self.eng, self.n = eng, n
+        s = libff_amd.sizes(curve, group)
+        self.s = s
+        self.d_bases = eng.malloc(n * s["affine_bytes"])
+        self.d_sc = eng.malloc(scalars.nbytes)
+        self.d_out = eng.malloc(s["g_bytes"])
+        eng.gen_bases_seq_device(curve, group, first, n, self.d_bases.value)
+        eng.h2d(self.d_sc, scalars)
+
+    def result(self):
+        self.eng.synchronize()
+        out = np.zeros(self.s["g_bytes"] // 8, dtype=np.uint64)
+        self.eng.d2h(out, self.d_out)
+        return out
+
+    def free(self):
+        for p in (self.d_bases, self.d_sc, self.d_out):
+            self.eng.free(p)
+
+
+@pytest.mark.parametrize("name,curve,group,log2n", [("alt_bn128_g1", 0, 1, 23), ("bls12_377_g1", 1, 1, 22)])
+def test_per_rank_shard_sizes_closed_form_and_sharding(engine, port, name, curve, group, log2n):
+    """configs[3]'s per-rank shard (alt_bn128 G1 2^23 = 2^26 / 8) and configs[2] (bls12_377 G1 2^22)
+    at full size: closed form, and the same input as two ranges on two contexts
+    (amdmsm_msm_device_multi; odd split so the last range takes a remainder) == unsharded."""
+    n = 1 << log2n
+    sc = port.scalars_sha512(curve, 0, n)
+    want = _closed_form_point(port, curve, group, sc, 0)
+    r = _Resident(engine, curve, group, n, 0, sc)
+    e2 = libff_amd.Engine(0)
+    try:
+        engine.msm_device(curve, group, r.d_bases.value, r.d_sc.value, n, r.d_out.value, out_form=libff_amd.OUT_AFFINE)
+        assert (r.result() == want).all()
+        # two ranges [0, one) and [one, n) with one = (n - 5) // 2: pointers into the same arrays
+        s = r.s
+        one = (n - 5) // 2
+        bases = [r.d_bases.value, r.d_bases.value + one * s["affine_bytes"]]
+        scal = [r.d_sc.value, r.d_sc.value + one * s["fr_bytes"]]
+        engine.h2d(r.d_out, np.zeros(s["g_bytes"] // 8, dtype=np.uint64))
+        libff_amd.msm_device_multi([engine, e2], curve, group, bases, scal, [one, n - one], r.d_out.value,
+                                   out_form=libff_amd.OUT_AFFINE)
+        assert (r.result() == want).all()
+    finally:
+        r.free()
+        e2.close()
+
+
+def test_config4_two_msms_issued_together(engine, port):
+    """configs[4] per-rank shard: bw6_761 G1 2^21 and bls12_377 G2 2^21 enqueued back to back on two
+    contexts (two streams) with no synchronisation in between, as a BW6/BLS12 prover issues
+    them; both checked against the closed form, and again after swapping the issue order."""
+    n = 1 << 21
+    e2 = libff_amd.Engine(0)
+    jobs = []
+    try:
+        for eng, (curve, group) in ((engine, (2, 1)), (e2, (1, 2))):
+            sc = port.scalars_sha512(curve, 12345, n)
+            jobs.append((eng, curve, group, _Resident(eng, curve, group, n, 7, sc), _closed_form_point(port, curve, group, sc, 7)))
+        for order in (jobs, jobs[::-1]):
+            for eng, curve, group, r, _ in order:
+                eng.h2d(r.d_out, np.zeros(r.s["g_bytes"] // 8, dtype=np.uint64))
+            for eng, curve, group, r, _ in order:   # asynchronous launches: both MSMs are in flight together
+                eng.msm_device(curve, group, r.d_bases.value, r.d_sc.value, n, r.d_out.value, out_form=libff_amd.OUT_AFFINE)
+            for eng, curve, group, r, want in order:
+                assert (r.result() == want).all(), (curve, group)
+    finally:
+        for j in jobs:
+            j[3].free()
+        e2.close()
+
+
+@pytest.mark.parametrize("name,curve,group,n", [("alt_bn128_g1", 0, 1, 70001), ("bls12_377_g2", 1, 2, 4099),
+                                                 ("bw6_761_g1", 2, 1, 3001)])
+def test_multi_exp_multi_c_abi(engine, port, name, curve, group, n):
+    """amdmsm_multi_exp_multi from host vectors: ndev = 1, two and three contexts on one device
+    (remainder in the last range), normal- and special-form bases, vs the oracle; n < ndev."""
+    bases = port.bases_seq(curve, group, n, first=21)
+    sc = port.scalars_sha512(curve, 4242, n)
+    want = port.multi_exp(curve, group, bases, sc, port.BDLO12_SIGNED, 1, chunks=8, omp=True)
+    extra = [libff_amd.Engine(0), libff_amd.Engine(0)]
+    try:
+        for engines in ([engine], [engine, extra[0]], [engine] + extra):
+            got = libff_amd.multi_exp_multi(engines, curve, group, bases, sc, base_form=multi_exp_base_form_special)
+            assert (got == want).all(), len(engines)
+        # normal-form bases (3 * P_i, Z != 1): shared inversions per range
+        nb = engine.group_op(curve, group, 0, engine.group_op(curve, group, 2, bases[:500]), bases[:500])
+        want_n = port.multi_exp(curve, group, nb, sc[:500], port.BDLO12_SIGNED, 0)
+        got = libff_amd.multi_exp_multi([engine, extra[0]], curve, group, nb, sc[:500], base_form=multi_exp_base_form_normal)
+        assert (got == want_n).all()
+        # fewer points than contexts: falls back to one call (multiexp.tcc:656)
+        got = libff_amd.multi_exp_multi([engine] + extra, curve, group, bases[:2], sc[:2], base_form=multi_exp_base_form_special)
+        assert (got == port.multi_exp(curve, group, bases[:2], sc[:2], port.BDLO12_SIGNED, 1)).all()
+        with pytest.raises(libff_amd.AmdMsmError):
+            libff_amd.multi_exp_multi([engine, engine], curve, group, bases, sc)
+    finally:
+        for e in extra:
+            e.close()
+
+
+def test_resident_bases_registry(engine, port):
+    """amdmsm_register_bases: later calls on the registered vector (or on row ranges of it) read the
+    copy in HBM -- proven by changing the host array after registration: the result keeps following
+    the registered content until amdmsm_invalidate_bases, then follows the host array again."""
+    curve, group, n = 0, 1, 5000
+    bases = np.ascontiguousarray(port.bases_seq(curve, group, n, first=0))
+    other = port.bases_seq(curve, group, n, first=100000)
+    sc1, sc2 = port.scalars_sha512(curve, 1, n), port.scalars_sha512(curve, 2, n)
+    w1 = port.multi_exp(curve, group, bases, sc1, port.BDLO12_SIGNED, 1, chunks=4, omp=True)
+    w2 = port.multi_exp(curve, group, bases, sc2, port.BDLO12_SIGNED, 1, chunks=4, omp=True)
+    h = engine.register_bases(curve, group, bases, multi_exp_base_form_special)
+    try:
+        assert (engine.multi_exp(curve, group, bases, sc1, base_form=multi_exp_base_form_special) == w1).all()
+        assert (engine.multi_exp(curve, group, bases, sc2, base_form=multi_exp_base_form_special) == w2).all()
+        # a row range of the registered vector (what a chunked / multi-GPU caller passes)
+        sub = bases[1000:3500]
+        wsub = port.multi_exp(curve, group, sub, sc1[1000:3500], port.BDLO12_SIGNED, 1)
+        assert (engine.multi_exp(curve, group, sub, sc1[1000:3500], base_form=multi_exp_base_form_special) == wsub).all()
+        # a different form is a different import: not served from the registration
+        assert (engine.multi_exp(curve, group, bases, sc1, base_form=multi_exp_base_form_normal) == w1).all()
+        keep = bases.copy()
+        bases[:] = other     # the registration still holds the old content
+        assert (engine.multi_exp(curve, group, bases, sc1, base_form=multi_exp_base_form_special) == w1).all()
+        engine.invalidate_bases(bases)
+        w_other = port.multi_exp(curve, group, other, sc1, port.BDLO12_SIGNED, 1, chunks=4, omp=True)
+        assert (engine.multi_exp(curve, group, bases, sc1, base_form=multi_exp_base_form_special) == w_other).all()
+        bases[:] = keep
+        with pytest.raises(libff_amd.AmdMsmError):
+            engine.unregister_bases(h)       # dropped by the invalidation
+        h = engine.register_bases(curve, group, bases, multi_exp_base_form_special)
+        assert (engine.multi_exp(curve, group, bases, sc2, base_form=multi_exp_base_form_special) == w2).all()
+    finally:
+        engine.invalidate_bases(None)
+
+
+def test_filter_one_zero_counts_on_device_large(engine, port):
+    """multi_exp_filter_one_zero's three counts (multiexp.tcc:713-757) come from device counters;
+    2^20 witness-like scalars (most of them 0 / 1), Montgomery and plain representation."""
+    curve, group, n = 0, 1, 1 << 20
+    rng = np.random.default_rng(3)
+    sc = port.scalars_sha512(curve, 0, n)
+    zo = small_scalars_mont(port, curve, [0, 1])
+    pick = rng.integers(0, 5, size=n)
+    sc[pick == 0] = zo[0]
+    sc[(pick == 1) | (pick == 2)] = zo[1]
+    bases = engine.gen_bases_seq(curve, group, n, first=0)
+    want = port.multi_exp(curve, group, bases, sc, port.BDLO12_SIGNED, 1, chunks=16, omp=True)
+    got, stats = engine.multi_exp_filter_one_zero(curve, group, bases, sc, base_form=multi_exp_base_form_special)
+    assert (got == want).all()
+    assert stats == {"skipped": int((pick == 0).sum()), "ones": int(((pick == 1) | (pick == 2)).sum()),
+                     "other": int((pick >= 3).sum())}
+    plain = port.fr_as_bigint(curve, sc)
+    got, stats2 = engine.multi_exp_filter_one_zero(curve, group, bases, plain, base_form=multi_exp_base_form_special,
+                                                   scalars_plain=True)
+    assert (got == want).all() and stats2 == stats
+
+
+def test_precomputed_rejects_unservable_num_digits(engine, port):
+    """(c, num_digits) pairs the kernels cannot serve are refused up front, and a non-default
+    num_digits (one more than ceil(bits / c): keeps the final carry) is served."""
+    curve, group, n, c = 0, 1, 600, 11
+    D = libff_amd.precompute_num_digits(curve, c)
+    b = port.bases_seq(curve, group, n, first=3)
+    s = port.scalars_sha512(curve, 5, n)
+    z = libff_amd.sizes(curve, group)
+    tab = engine.precompute_table(curve, group, b, c, num_digits=D + 1)
+    d_src, d_tab = engine.malloc(tab.nbytes), engine.malloc(tab.shape[0] * z["affine_bytes"])
+    d_sc, d_out = engine.malloc(s.nbytes), engine.malloc(z["g_bytes"])
+    try:
+        engine.h2d(d_src, tab)
+        engine.h2d(d_sc, s)
+        engine.import_bases_device(curve, group, d_src, tab.strides[0], 1, tab.shape[0], d_tab)
+        engine.msm_precomputed_device(curve, group, d_tab, d_sc, n, c, D + 1, d_out, out_form=libff_amd.OUT_AFFINE)
+        engine.synchronize()
+        out = np.zeros(z["g_bytes"] // 8, dtype=np.uint64)
+        engine.d2h(out, d_out)
+        assert (out == port.multi_exp(curve, group, b, s, port.BDLO12_SIGNED, 1, chunks=4, omp=True)).all()
+        for bad in (D + 2, 200, 512):
+            with pytest.raises(libff_amd.AmdMsmError):
+                engine.msm_precomputed_device(curve, group, d_tab, d_sc, n, c, bad, d_out)
+    finally:
+        for p in (d_src, d_tab, d_sc, d_out):
+            engine.free(p)
+
+
+def test_sharded_msm_nccl_world_size_one():
+    """ShardedMsm (libff_amd/distributed.py, what bench.py --gpus N runs) through the nccl backend
+    at world size 1, depth 1 and 2, with scalars that change every step: each result against the
+    oracle.  Child process: it initialises torch.distributed."""
+    import subprocess
+
+    code = r'''
+import os, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np, torch, torch.distributed as dist
+import libff_amd
+from libff_amd.distributed import ShardedMsm, numpy_words
+from oracle import port
+port.build()
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+curve, group, n = 0, 1, 20000
+eng = libff_amd.Engine(0)
+sz = libff_amd.sizes(curve, group)
+bases_h = port.bases_seq(curve, group, n, first=0)
+bases = torch.empty((n, sz["affine_bytes"] // 8), dtype=torch.int64, device=dev)
+eng.gen_bases_seq_device(curve, group, 0, n, bases.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+torch.cuda.synchronize()
+for depth in (1, 2):
+    msm = ShardedMsm(eng, curve, group, depth=depth)
+    outs, wants = [], []
+    for step in range(4):
+        sc_h = port.scalars_sha512(curve, 1000 * step + depth, n)
+        sc = torch.from_numpy(sc_h.view(np.int64)).to(dev)        # produced on the current stream
+        res, slot = msm.run(bases, sc, n, libff_amd.OUT_AFFINE)
+        msm.streams[slot %% depth].synchronize()
+        outs.append(numpy_words(res).copy())
+        wants.append(port.multi_exp(curve, group, bases_h, sc_h, port.BDLO12_SIGNED, 1, chunks=8, omp=True))
+    msm.synchronize()
+    for o, w in zip(outs, wants):
+        assert (o == w).all()
+dist.destroy_process_group()
+print("sharded-nccl-ok")
+''' % (REPO, os.path.join(REPO, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "sharded-nccl-ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])

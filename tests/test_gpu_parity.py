@@ -84,7 +84,7 @@ def test_multi_exp_small_like_reference_tests(engine, port, name, curve, group):
         for method in (multi_exp_method_BDLO12_signed, multi_exp_method_BDLO12):
             for form in (multi_exp_base_form_normal, multi_exp_base_form_special):
                 for chunks in (1, 2, 4):
-                    got = engine.multi_exp(curve, group, bases, scalars, method, form, chunks)
+                    got = engine.multi_exp(curve, group, bases, scalars, method, form, chunks, split_chunks=True)
                     assert (got == want).all(), (n, method, form, chunks)
 
 
@@ -94,7 +94,7 @@ def test_multi_exp_golden_vectors(engine, port, name, curve, group):
     bases, scalars = g[f"{name}/msm_sha256_bases"], g[f"{name}/msm_sha256_scalars"]
     want = g[f"{name}/msm_sha256"]
     assert (engine.multi_exp(curve, group, bases, scalars, base_form=multi_exp_base_form_special) == want).all()
-    assert (engine.multi_exp(curve, group, bases, scalars, base_form=multi_exp_base_form_normal, chunks=3) == want).all()
+    assert (engine.multi_exp(curve, group, bases, scalars, base_form=multi_exp_base_form_normal, chunks=3, split_chunks=True) == want).all()
     # window size must not change the group element
     for c in (2, 5, 9, 12):
         got = engine.multi_exp(curve, group, bases, scalars, base_form=multi_exp_base_form_special, window_bits=c)
@@ -186,7 +186,7 @@ def test_multi_exp_matches_oracle_seeded(engine, port, name, curve, group, n):
         want = port.multi_exp(curve, group, bases, sc, port.BDLO12_SIGNED, 1, chunks=8, omp=True)
         got = engine.multi_exp(curve, group, bases, sc, multi_exp_method_BDLO12_signed, multi_exp_base_form_special)
         assert (got == want).all()
-        got = engine.multi_exp(curve, group, bases, sc, multi_exp_method_BDLO12, multi_exp_base_form_normal, chunks=3)
+        got = engine.multi_exp(curve, group, bases, sc, multi_exp_method_BDLO12, multi_exp_base_form_normal, chunks=3, split_chunks=True)
         assert (got == want).all()
 
 
@@ -234,6 +234,9 @@ def test_full_size_closed_form_and_sharding(engine, port, name, curve, group, lo
     auto_c = libff_amd.plan(curve, group, n)["c"]
     got = engine.multi_exp(curve, group, bases, sc, base_form=multi_exp_base_form_special, window_bits=auto_c - 3)
     assert (got == want).all()
+    got = engine.multi_exp(curve, group, bases, sc, base_form=multi_exp_base_form_special, chunks=8, split_chunks=True)
+    assert (got == want).all()
+    # chunks as a plain hint (what libsnark passes): one MSM, same group element
     got = engine.multi_exp(curve, group, bases, sc, base_form=multi_exp_base_form_special, chunks=8)
     assert (got == want).all()
 
@@ -302,26 +305,27 @@ def _be_bytes(limbs_le):
     return np.frombuffer(np.ascontiguousarray(limbs_le, dtype=np.uint64).tobytes()[::-1], dtype=np.uint8)
 
 
-@pytest.mark.parametrize("name,curve,sym", [("alt_bn128_g1", 0, "alt_bn128_g1_multiexp"),
-                                             ("bls12_377_g1", 1, "bls12_377_g1_multiexp"),
-                                             ("bw6_761_g1", 2, "bw6_761_g1_multiexp")])
-def test_ffi_multiexp(engine, port, name, curve, sym):
-    """The FFI-convention symbols (include/libff_amd_ffi.h): big-endian plain affine in and out,
-    reference validation rules (ffi_serialization.tcc:150-171), false + untouched output on error.
-    Expected bytes come from the oracle's restatement of group_element_write."""
+@pytest.mark.parametrize("name,curve,group", [g for g in GROUPS if g[1] != 3])
+def test_ffi_multiexp(engine, port, name, curve, group):
+    """The FFI-convention symbols (include/libff_amd_ffi.h), G1 and G2: big-endian plain affine in
+    and out (Fq2 coordinates c1 then c0), reference validation rules (ffi_serialization.tcc:150-171:
+    sizes, range, is_well_formed, is_in_safe_subgroup), false + untouched output on error.
+    Expected bytes come from the oracle's restatement of group_element_write; the points that
+    are on the curve but outside the safe subgroup are reference-generated fixtures
+    (curve_points, with the reference's own verdicts in curve_points_flags)."""
     import ctypes
 
     lib = engine.lib
-    fn = getattr(lib, sym)
+    fn = getattr(lib, f"{name}_multiexp")
     fn.restype = ctypes.c_bool
-    n = 300 if curve != 2 else 120
-    bases = port.bases_seq(curve, 1, n, first=17)
+    n = {1: 300, 2: 120}[group] if curve != 2 else 100
+    bases = port.bases_seq(curve, group, n, first=17)
     sc = port.scalars_sha512(curve, 900, n)
-    s = port.sizes(curve, 1)
+    s = port.sizes(curve, group)
     cb, fb = s["coord_bytes"], s["fr_bytes"]
-    bases_buf = np.concatenate([port.ffi_group_write(curve, 1, b) for b in bases])
+    bases_buf = np.concatenate([port.ffi_group_write(curve, group, b) for b in bases])
     sc_buf = np.concatenate([port.ffi_fr_write(curve, x) for x in sc])
-    want = port.ffi_group_write(curve, 1, port.multi_exp(curve, 1, bases, sc, port.BDLO12_SIGNED, 1))
+    want = port.ffi_group_write(curve, group, port.multi_exp(curve, group, bases, sc, port.BDLO12_SIGNED, 1))
     out = np.zeros(2 * cb, dtype=np.uint8)
 
     def call(b, sv, o):
@@ -332,12 +336,12 @@ def test_ffi_multiexp(engine, port, name, curve, sym):
     assert call(bases_buf, sc_buf, out)
     assert (out == want).all()
     # a zero base ((0, 1) encoding) is accepted and ignored
-    zero_enc = port.ffi_group_write(curve, 1, port.group_consts(curve, 1)[1])
+    zero_enc = port.ffi_group_write(curve, group, port.group_consts(curve, group)[1])
     b2 = bases_buf.copy()
     b2[: 2 * cb] = zero_enc
     bz = bases.copy()
-    bz[0] = port.group_consts(curve, 1)[1]
-    want2 = port.ffi_group_write(curve, 1, port.multi_exp(curve, 1, bz, sc, port.BDLO12_SIGNED, 1))
+    bz[0] = port.group_consts(curve, group)[1]
+    want2 = port.ffi_group_write(curve, group, port.multi_exp(curve, group, bz, sc, port.BDLO12_SIGNED, 1))
     assert call(b2, sc_buf, out) and (out == want2).all()
     # failures: wrong sizes, coordinate >= modulus, point off the curve, scalar >= r
     sentinel = np.full(2 * cb, 0xA5, dtype=np.uint8)
@@ -358,6 +362,21 @@ def test_ffi_multiexp(engine, port, name, curve, sym):
             s3[3 * fb: 4 * fb] = 0xFF
         assert not call(b3, s3, o), mutate
         assert (o == 0xA5).all(), mutate
+    # on the curve, but is_in_safe_subgroup() is false in the reference (cofactor torsion): rejected
+    # exactly where the reference rejects (alt_bn128 G1 has cofactor 1: every curve point passes)
+    cp, flags = golden()[f"{name}/curve_points"], golden()[f"{name}/curve_points_flags"]
+    for k in range(cp.shape[0]):
+        assert flags[k] & 1
+        b4, o = bases_buf.copy(), sentinel.copy()
+        b4[9 * 2 * cb: 10 * 2 * cb] = port.ffi_group_write(curve, group, cp[k])
+        ok = call(b4, sc_buf, o)
+        assert ok == bool(flags[k] & 2), (k, int(flags[k]))
+        if ok:
+            bb = bases.copy()
+            bb[9] = cp[k]
+            assert (o == port.ffi_group_write(curve, group, port.multi_exp(curve, group, bb, sc, port.BDLO12_SIGNED, 1))).all()
+        else:
+            assert (o == 0xA5).all()
     # empty input -> zero = (0, 1)
     assert call(np.zeros(0, dtype=np.uint8), np.zeros(0, dtype=np.uint8), out)
     assert (out == zero_enc).all()

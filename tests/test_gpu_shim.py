@@ -20,6 +20,22 @@ def test_template_shim_with_real_libff_types():
     print(r.stdout[-3000:])
     print(r.stderr[-2000:])
     assert r.returncode == 0 and "SHIM CHECK PASSED" in r.stdout
+    # the 2^20-point call with chunks = 16 (one MSM, not 16) and the registered-bases call ran
+    assert "chunks=16" in r.stdout and "filter_one_zero ok" in r.stdout
+
+
+@pytest.mark.gpu
+def test_template_shim_multi_device_route():
+    """The same program with two engine contexts configured (AMDMSM_DEVICES=0,0: both on the one GPU
+    of the test box) and a split threshold low enough that every case with >= 200 points goes
+    through amdmsm_multi_exp_multi (multiexp.tcc:655-687 with chunk = context)."""
+    if not os.path.exists(BIN):
+        pytest.skip("oracle/_ref/shim_check not built (needs the reference sources at build time)")
+    env = dict(os.environ, AMDMSM_DEVICES="0,0", SHIM_CHECK_MIN_SPLIT="100", SHIM_CHECK_SKIP_LARGE="1")
+    r = subprocess.run([BIN], capture_output=True, text=True, timeout=900, env=env)
+    print(r.stdout[-3000:])
+    print(r.stderr[-2000:])
+    assert r.returncode == 0 and "SHIM CHECK PASSED" in r.stdout
 
 
 def test_shim_header_compiles_against_reference():

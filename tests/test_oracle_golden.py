@@ -177,6 +177,21 @@ def test_ffi_codec_roundtrip(port, name, curve, group):
 
 
 @pytest.mark.parametrize("name,curve,group", GROUPS)
+def test_ffi_read_rejects_points_outside_the_safe_subgroup(port, name, curve, group):
+    """group_element_read accepts a point only if is_well_formed() && is_in_safe_subgroup()
+    (ffi_serialization.tcc:165).  Fixtures: curve points found by scanning x in the reference,
+    with the reference's own verdicts -- on the curve, and in the subgroup only where the
+    cofactor is 1 (alt_bn128 G1).  The restatement must give the same verdict point for point."""
+    g = golden()
+    pts, flags = g[f"{name}/curve_points"], g[f"{name}/curve_points_flags"]
+    assert pts.shape[0] == 6 and (flags & 1).all()
+    assert bool((flags & 2).all()) == (name == "alt_bn128_g1")
+    for k in range(pts.shape[0]):
+        back = port.ffi_group_read(curve, group, port.ffi_group_write(curve, group, pts[k]))
+        assert (back is not None) == bool(flags[k] & 2)
+
+
+@pytest.mark.parametrize("name,curve,group", GROUPS)
 def test_batch_exp(port, name, curve, group):
     """get_window_table + batch_exp / batch_exp_with_coeff (multiexp.tcc:809-947)."""
     g = golden()

@@ -89,7 +89,7 @@ def main():
         form = int(rng.integers(2))
         chunks = int(rng.choice([1, 1, 2, 3, 8]))
         want = port.multi_exp(curve, group, bases, sc, port.BDLO12_SIGNED, 1, chunks=4, omp=True)
-        got = eng.multi_exp(curve, group, bases, sc, base_form=form, window_bits=c, chunks=chunks)
+        got = eng.multi_exp(curve, group, bases, sc, base_form=form, window_bits=c, chunks=chunks, split_chunks=True)
         it += 1
         if not (got == want).all():
             fails += 1
