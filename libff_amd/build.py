@@ -23,6 +23,9 @@ GROUPS = ["alt_bn128_g1", "alt_bn128_g2", "bls12_377_g1", "bls12_377_g2", "bw6_7
 #   AMDMSM_BENCH_BOTH  also build the inline variants of the throughput probes
 GROUP_FLAGS = {g: ["-DAMDMSM_HOT_INLINE=1", "-DAMDMSM_BENCH_BOTH=1"] for g in GROUPS}
 GROUP_FLAGS["alt_bn128_g2"] = GROUP_FLAGS["alt_bn128_g2"] + ["-DAMDMSM_ACC_LAZY=0"]   # measured slower there
+# register budget of the bucket-accumulation kernel: 4 waves per SIMD (128 VGPRs, 3 dwords of
+# scratch) instead of the 137 VGPRs / 3 waves the compiler picks unconstrained: -4 % at 2^20
+GROUP_FLAGS["alt_bn128_g1"] = GROUP_FLAGS["alt_bn128_g1"] + ["-DAMDMSM_ACC_WAVES=4"]
 ARCH = "gfx950"
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-I" + INCLUDE, "-I" + CSRC,
           "-Wno-unused-result"]
@@ -58,6 +61,8 @@ def build(force=False, verbose=True, jobs=None):
     tasks = []
     objs = []
     groups = [g for g in os.environ.get("AMDMSM_GROUPS", ",".join(GROUPS)).split(",") if g]
+    # AMDMSM_EXTRA_FLAGS="-DAMDMSM_ACC_WAVES=4 ...": experiment knobs appended to every group TU
+    extra = os.environ.get("AMDMSM_EXTRA_FLAGS", "").split()
     for g in groups:
         if g not in GROUPS:
             raise RuntimeError(f"unknown group {g!r}")
@@ -65,7 +70,7 @@ def build(force=False, verbose=True, jobs=None):
         objs.append(o)
         if force or _newer(o, DEVICE_DEPS):
             tasks.append([cc, *COMMON, "-c", os.path.join(CSRC, "msm_group.hip"),
-                          f"-DAMDMSM_GROUP={g}", f"-DAMDMSM_VT=vt_{g}", *GROUP_FLAGS.get(g, []), "-o", o])
+                          f"-DAMDMSM_GROUP={g}", f"-DAMDMSM_VT=vt_{g}", *GROUP_FLAGS.get(g, []), *extra, "-o", o])
     for src in ("engine", "ffi"):
         eo = os.path.join(OBJ, f"{src}.o")
         objs.append(eo)

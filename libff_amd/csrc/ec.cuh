@@ -342,9 +342,7 @@ AMDMSM_DEV void xyzz_madd_lz(Xyzz<E>& acc, const Aff<E>& p) {
     el_sub_lz(t, t, q);
     el_sub_lz(acc.x, t, q);          // X3 = R^2 - PPP - 2Q
     el_sub_lz(q, q, acc.x);
-    el_mul_lz(q, r, q);              // R*(Q - X3)
-    el_mul_lz(t, acc.y, ppp);        // Y1*PPP
-    el_sub_lz(acc.y, q, t);          // Y3
+    el_mul_sub_mul_lz(acc.y, r, q, acc.y, ppp);   // Y3 = R*(Q - X3) - Y1*PPP, one reduction
 }
 
 // r = a + b, add-2008-s (r may alias a)

@@ -257,9 +257,42 @@ AMDMSM_DEV void fp_mul(Fp<P, I>& r, const Fp<P, I>& a, const Fp<P, I>& b) {
     }
 }
 
+// Fp_model::squared (fp.tcc:632-677).  No dedicated squaring kernel: taking each cross product
+// a[i]*a[j] (i < j) once means doubling it, and with full 32-bit limbs neither operand has a spare
+// bit (2*a[i] needs 33), so the doubling has to be done on a separate per-column accumulator
+// (shift a 96-bit value, add it into the running column: ~6 issues x 2N columns) -- which costs
+// what the N(N-1)/2 saved multiply-accumulate pairs would have saved.  (Doubling the operand as
+// a whole N-word integer is wrong for a partial sum over i < j: the carry bit that moves from
+// limb i-1 to limb i changes which limbs it meets.)
 template <class P, bool I>
 AMDMSM_DEV void fp_sqr(Fp<P, I>& r, const Fp<P, I>& a) {
     fp_mul(r, a, a);
+}
+
+// ---- sum of two products with ONE Montgomery reduction ------------------------------------------
+// (a*b + c*d) * R^-1: column k gathers a[i]*b[k-i] + c[i]*d[k-i] + m[i]*p[k-i]; the reduction half
+// (N^2 of the 4 N^2 multiply-accumulates of two separate products) is paid once.  Operands below
+// 2p give a result below p (8p/R + 1): below 2p when p < R/8, otherwise (alt_bn128: 2.51 p) one
+// conditional subtraction of 2p brings it back into [0, 2p).
+template <class P, int K>
+AMDMSM_DEV void fp_mul2_column(uint64_t& lo, uint32_t& hi, uint32_t* m, uint32_t* t, const uint32_t* a, const uint32_t* b,
+                               const uint32_t* c, const uint32_t* d) {
+    constexpr int N = P::N;
+    if constexpr (K < N) {
+        mac_range_vv<K, 0, K + 1>(lo, hi, a, b);
+        mac_range_vv<K, 0, K + 1>(lo, hi, c, d);
+        mac_range_vs<P, K, 0, K>(lo, hi, m);
+        m[K] = (uint32_t)lo * P::INV;
+        mac_chain<1>::vs(lo, hi, m[K], P::P[0]);
+    } else {
+        mac_range_vv<K, K - N + 1, N>(lo, hi, a, b);
+        mac_range_vv<K, K - N + 1, N>(lo, hi, c, d);
+        mac_range_vs<P, K, K - N + 1, N>(lo, hi, m);
+        t[K - N] = (uint32_t)lo;
+    }
+    lo = (lo >> 32) | ((uint64_t)hi << 32);
+    hi = 0;
+    if constexpr (K + 1 < 2 * N) fp_mul2_column<P, K + 1>(lo, hi, m, t, a, b, c, d);
 }
 
 // ---- almost-reduced arithmetic: values in [0, 2p) ----------------------------------------
@@ -277,6 +310,30 @@ AMDMSM_DEV void fp_mul_lz(Fp<P, I>& r, const Fp<P, I>& a, const Fp<P, I>& b) {
     static_assert(P::P[P::N - 1] < 0x40000000u, "needs 4p <= 2^(32N)");
     if constexpr (I) fp_mul_core<P, false>(r.v, a.v, b.v);
     else fp_mul(r, a, b);
+}
+template <class P, bool I>
+AMDMSM_DEV void fp_sqr_lz(Fp<P, I>& r, const Fp<P, I>& a) {
+    fp_mul_lz(r, a, a);
+}
+// r = a*b + c*d in the almost-reduced domain (all operands and the result in [0, 2p))
+template <class P, bool I>
+AMDMSM_DEV void fp_mul2_lz(Fp<P, I>& r, const Fp<P, I>& a, const Fp<P, I>& b, const Fp<P, I>& c, const Fp<P, I>& d) {
+    static_assert(I, "inline element types only");
+    constexpr int N = P::N;
+    uint32_t m[N], t[N];
+    uint64_t lo = 0;
+    uint32_t hi = 0;
+    fp_mul2_column<P, 0>(lo, hi, m, t, a.v, b.v, c.v, d.v);
+    if constexpr (P::P[N - 1] >= 0x20000000u) {   // p >= R/8: the sum may reach 2.51 p
+        uint32_t dd[N];
+        uint32_t borrow = 0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) dd[i] = subb32(t[i], fp_2p_limb<P>(i), borrow);
+#pragma unroll
+        for (int i = 0; i < N; ++i) t[i] = borrow ? t[i] : dd[i];
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.v[i] = t[i];
 }
 template <class P, bool I>
 AMDMSM_DEV void fp_add_lz(Fp<P, I>& r, const Fp<P, I>& a, const Fp<P, I>& b) {

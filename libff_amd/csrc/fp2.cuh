@@ -177,7 +177,21 @@ template <class P, int NR, bool I> AMDMSM_DEV void el_store(uint32_t* p, const F
 
 // ---- almost-reduced ([0, 2p) per component) overload set, see fp.cuh ------------------------
 template <class P, bool I> AMDMSM_DEV void el_mul_lz(Fp<P, I>& r, const Fp<P, I>& a, const Fp<P, I>& b) { fp_mul_lz(r, a, b); }
-template <class P, bool I> AMDMSM_DEV void el_sqr_lz(Fp<P, I>& r, const Fp<P, I>& a) { fp_mul_lz(r, a, a); }
+template <class P, bool I> AMDMSM_DEV void el_sqr_lz(Fp<P, I>& r, const Fp<P, I>& a) { fp_sqr_lz(r, a); }
+// r = a*b - c*d  (one reduction where the element type allows it)
+template <class P, bool I>
+AMDMSM_DEV void el_mul_sub_mul_lz(Fp<P, I>& r, const Fp<P, I>& a, const Fp<P, I>& b, const Fp<P, I>& c, const Fp<P, I>& d) {
+    if constexpr (I) {
+        Fp<P, I> nc;
+        fp_neg_lz(nc, c);
+        fp_mul2_lz(r, a, b, nc, d);
+    } else {
+        Fp<P, I> t1, t2;
+        fp_mul_lz(t1, a, b);
+        fp_mul_lz(t2, c, d);
+        fp_sub_lz(r, t1, t2);
+    }
+}
 template <class P, bool I> AMDMSM_DEV void el_sub_lz(Fp<P, I>& r, const Fp<P, I>& a, const Fp<P, I>& b) { fp_sub_lz(r, a, b); }
 template <class P, bool I> AMDMSM_DEV bool el_is_zero_lz(const Fp<P, I>& a) { return fp_is_zero_lz(a); }
 template <class P, bool I> AMDMSM_DEV void el_canon(Fp<P, I>& a) { fp_canon(a); }
@@ -220,6 +234,15 @@ AMDMSM_DEV void el_sqr_lz(Fp2<P, NR, I>& r, const Fp2<P, NR, I>& x) {
     fp_mul_nr_lz<P, NR, I>(t, ab);
     fp_sub_lz(r.c0, s1, t);
     fp_add_lz(r.c1, ab, ab);
+}
+template <class P, int NR, bool I>
+AMDMSM_DEV void el_mul_sub_mul_lz(Fp2<P, NR, I>& r, const Fp2<P, NR, I>& a, const Fp2<P, NR, I>& b, const Fp2<P, NR, I>& c,
+                                  const Fp2<P, NR, I>& d) {
+    Fp2<P, NR, I> t1, t2;
+    el_mul_lz(t1, a, b);
+    el_mul_lz(t2, c, d);
+    fp_sub_lz(r.c0, t1.c0, t2.c0);
+    fp_sub_lz(r.c1, t1.c1, t2.c1);
 }
 template <class P, int NR, bool I>
 AMDMSM_DEV void el_sub_lz(Fp2<P, NR, I>& r, const Fp2<P, NR, I>& a, const Fp2<P, NR, I>& b) {

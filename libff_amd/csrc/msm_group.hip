@@ -55,6 +55,11 @@ using FR = typename GP::fr;
 #ifndef AMDMSM_ACC_LAZY
 #define AMDMSM_ACC_LAZY 1
 #endif
+// minimum waves per SIMD the bucket-accumulation kernel is compiled for (register budget:
+// 512 / waves, in granules of 8)
+#ifndef AMDMSM_ACC_WAVES
+#define AMDMSM_ACC_WAVES 1
+#endif
 template <int DEG, bool I> struct coord_sel;
 template <bool I> struct coord_sel<1, I> { using type = Fp<FQ, I>; };
 template <bool I> struct coord_sel<2, I> { using type = Fp2<FQ, GP::NR_SMALL == 0 ? -1 : GP::NR_SMALL, I>; };
@@ -740,7 +745,7 @@ AMDMSM_DEV uint32_t bucket_of_entry(const uint32_t* __restrict__ e, uint32_t B, 
     return l;
 }
 
-__global__ void __launch_bounds__(TPB) k_accumulate(const uint32_t* __restrict__ ends, const uint32_t* __restrict__ lists,
+__global__ void __launch_bounds__(TPB, AMDMSM_ACC_WAVES) k_accumulate(const uint32_t* __restrict__ ends, const uint32_t* __restrict__ lists,
                                                     size_t list_stride, const uint32_t* __restrict__ bases,
                                                     uint32_t* __restrict__ buckets, uint32_t* __restrict__ part_first,
                                                     uint32_t* __restrict__ part_last, uint32_t* __restrict__ cont_bucket,
