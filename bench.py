@@ -100,9 +100,11 @@ def self_launch(args):
     sys.exit(r.returncode)
 
 
-ARGS = parse_args()
-if ARGS.gpus > 1 and "WORLD_SIZE" not in os.environ:
-    self_launch(ARGS)
+ARGS = None
+if __name__ == "__main__":
+    ARGS = parse_args()
+    if ARGS.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(ARGS)   # does not return
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402

@@ -22,10 +22,18 @@ GROUPS = ["alt_bn128_g1", "alt_bn128_g2", "bls12_377_g1", "bls12_377_g2", "bw6_7
 #   AMDMSM_HOT_INLINE  inline the Montgomery product inside the bucket-accumulation loop
 #   AMDMSM_BENCH_BOTH  also build the inline variants of the throughput probes
 GROUP_FLAGS = {g: ["-DAMDMSM_HOT_INLINE=1", "-DAMDMSM_BENCH_BOTH=1"] for g in GROUPS}
-GROUP_FLAGS["alt_bn128_g2"] = GROUP_FLAGS["alt_bn128_g2"] + ["-DAMDMSM_ACC_LAZY=0"]   # measured slower there
 # register budget of the bucket-accumulation kernel: 4 waves per SIMD (128 VGPRs, 3 dwords of
 # scratch) instead of the 137 VGPRs / 3 waves the compiler picks unconstrained: -4 % at 2^20
 GROUP_FLAGS["alt_bn128_g1"] = GROUP_FLAGS["alt_bn128_g1"] + ["-DAMDMSM_ACC_WAVES=4"]
+# wide fields: unconstrained, the kernel takes 256 VGPRs plus 50..125 AGPRs as spill space and
+# runs ONE wave per SIMD; capped at 256 registers (two waves per SIMD, a little scratch) it is
+# 23-25 % faster (bls12_377 G2 2^21: 28.1 -> 22.9 ms, bw6_761 G1 2^21: 43.8 -> 35.0 ms);
+# 12-limb G1: 168 registers / three waves, +4 %.  alt_bn128 G2 is fastest unconstrained
+# (249 VGPRs, two waves).
+for _g in ("bls12_377_g2", "bls12_381_g2", "bw6_761_g1", "bw6_761_g2"):
+    GROUP_FLAGS[_g] = GROUP_FLAGS[_g] + ["-DAMDMSM_ACC_WAVES=2"]
+for _g in ("bls12_377_g1", "bls12_381_g1"):
+    GROUP_FLAGS[_g] = GROUP_FLAGS[_g] + ["-DAMDMSM_ACC_WAVES=3"]
 ARCH = "gfx950"
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-I" + INCLUDE, "-I" + CSRC,
           "-Wno-unused-result"]

@@ -274,25 +274,25 @@ AMDMSM_DEV void fp_sqr(Fp<P, I>& r, const Fp<P, I>& a) {
 // (N^2 of the 4 N^2 multiply-accumulates of two separate products) is paid once.  Operands below
 // 2p give a result below p (8p/R + 1): below 2p when p < R/8, otherwise (alt_bn128: 2.51 p) one
 // conditional subtraction of 2p brings it back into [0, 2p).
-template <class P, int K>
-AMDMSM_DEV void fp_mul2_column(uint64_t& lo, uint32_t& hi, uint32_t* m, uint32_t* t, const uint32_t* a, const uint32_t* b,
-                               const uint32_t* c, const uint32_t* d) {
+template <class P, int K, int T>
+AMDMSM_DEV void fp_dot_column(uint64_t& lo, uint32_t& hi, uint32_t* m, uint32_t* t, const uint32_t* const (&a)[T],
+                              const uint32_t* const (&b)[T]) {
     constexpr int N = P::N;
     if constexpr (K < N) {
-        mac_range_vv<K, 0, K + 1>(lo, hi, a, b);
-        mac_range_vv<K, 0, K + 1>(lo, hi, c, d);
+#pragma unroll
+        for (int j = 0; j < T; ++j) mac_range_vv<K, 0, K + 1>(lo, hi, a[j], b[j]);
         mac_range_vs<P, K, 0, K>(lo, hi, m);
         m[K] = (uint32_t)lo * P::INV;
         mac_chain<1>::vs(lo, hi, m[K], P::P[0]);
     } else {
-        mac_range_vv<K, K - N + 1, N>(lo, hi, a, b);
-        mac_range_vv<K, K - N + 1, N>(lo, hi, c, d);
+#pragma unroll
+        for (int j = 0; j < T; ++j) mac_range_vv<K, K - N + 1, N>(lo, hi, a[j], b[j]);
         mac_range_vs<P, K, K - N + 1, N>(lo, hi, m);
         t[K - N] = (uint32_t)lo;
     }
     lo = (lo >> 32) | ((uint64_t)hi << 32);
     hi = 0;
-    if constexpr (K + 1 < 2 * N) fp_mul2_column<P, K + 1>(lo, hi, m, t, a, b, c, d);
+    if constexpr (K + 1 < 2 * N) fp_dot_column<P, K + 1, T>(lo, hi, m, t, a, b);
 }
 
 // ---- almost-reduced arithmetic: values in [0, 2p) ----------------------------------------
@@ -315,16 +315,35 @@ template <class P, bool I>
 AMDMSM_DEV void fp_sqr_lz(Fp<P, I>& r, const Fp<P, I>& a) {
     fp_mul_lz(r, a, a);
 }
-// r = a*b + c*d in the almost-reduced domain (all operands and the result in [0, 2p))
-template <class P, bool I>
-AMDMSM_DEV void fp_mul2_lz(Fp<P, I>& r, const Fp<P, I>& a, const Fp<P, I>& b, const Fp<P, I>& c, const Fp<P, I>& d) {
+// r = sum_j a_j * b_j (T products, ONE reduction) in the almost-reduced domain: factors at most 2p
+// each (F2 = largest product of two factor bounds in units of p^2: 4 for plain operands), result
+// in [0, 2p).  The unreduced bound is p (T F2 p/R + 1); whatever exceeds 2p is removed by
+// conditional subtractions of 2p, whose number is fixed at compile time from the modulus.
+template <class P, int T, int F2 = 4>
+constexpr int fp_dot_subs() {
+    // (T * F2 * p / R + 1) p, p / R < (top + 1) / 2^32; subtractions of 2p needed to get below 2p
+    const double bound = (double)T * F2 * ((double)P::P[P::N - 1] + 1.0) / 4294967296.0 + 1.0;
+    int n = 0;
+    double b = bound;
+    while (b > 2.0) {
+        b = (b - 2.0 > 2.0) ? b - 2.0 : 2.0;   // after one subtraction the value is below max(b - 2, 2)
+        ++n;
+        if (b <= 2.0) break;
+    }
+    return bound <= 2.0 ? 0 : n;
+}
+template <class P, int T, int F2, bool I>
+AMDMSM_DEV void fp_dot_lz(Fp<P, I>& r, const uint32_t* const (&a)[T], const uint32_t* const (&b)[T]) {
     static_assert(I, "inline element types only");
     constexpr int N = P::N;
+    static_assert((double)T * F2 * ((double)P::P[N - 1] + 1.0) / 4294967296.0 + 1.0 < 4294967296.0 / ((double)P::P[N - 1] + 1.0),
+                  "the unreduced sum must fit N words");
     uint32_t m[N], t[N];
     uint64_t lo = 0;
     uint32_t hi = 0;
-    fp_mul2_column<P, 0>(lo, hi, m, t, a.v, b.v, c.v, d.v);
-    if constexpr (P::P[N - 1] >= 0x20000000u) {   // p >= R/8: the sum may reach 2.51 p
+    fp_dot_column<P, 0, T>(lo, hi, m, t, a, b);
+#pragma unroll
+    for (int k = 0; k < fp_dot_subs<P, T, F2>(); ++k) {
         uint32_t dd[N];
         uint32_t borrow = 0;
 #pragma unroll
@@ -334,6 +353,13 @@ AMDMSM_DEV void fp_mul2_lz(Fp<P, I>& r, const Fp<P, I>& a, const Fp<P, I>& b, co
     }
 #pragma unroll
     for (int i = 0; i < N; ++i) r.v[i] = t[i];
+}
+// r = a*b + c*d; F2: see fp_dot_lz (4 when every factor is below 2p)
+template <class P, bool I, int F2 = 4>
+AMDMSM_DEV void fp_mul2_lz(Fp<P, I>& r, const Fp<P, I>& a, const Fp<P, I>& b, const Fp<P, I>& c, const Fp<P, I>& d) {
+    const uint32_t* const x[2] = {a.v, c.v};
+    const uint32_t* const y[2] = {b.v, d.v};
+    fp_dot_lz<P, 2, F2>(r, x, y);
 }
 template <class P, bool I>
 AMDMSM_DEV void fp_add_lz(Fp<P, I>& r, const Fp<P, I>& a, const Fp<P, I>& b) {
@@ -373,6 +399,33 @@ AMDMSM_DEV void fp_neg_lz(Fp<P, I>& r, const Fp<P, I>& a) {
     uint32_t borrow = 0;
 #pragma unroll
     for (int i = 0; i < P::N; ++i) r.v[i] = subb32(fp_2p_limb<P>(i), a.v[i], borrow) & mask;
+}
+// limb k of K * p (K small, K * p < 2^(32N))
+template <class P, int K>
+AMDMSM_DEV constexpr uint32_t fp_kp_limb(int k) {
+    uint64_t carry = 0;
+    uint32_t r = 0;
+    for (int i = 0; i <= k; ++i) {
+        const uint64_t v = (uint64_t)P::P[i] * (uint64_t)K + carry;
+        r = (uint32_t)v;
+        carry = v >> 32;
+    }
+    return r;
+}
+// r = K*p - a as plain integers, for a <= K*p: a representative of -a that is only ever used as a
+// factor of a fused product sum (never compared, never stored)
+template <class P, int K, bool I>
+AMDMSM_DEV void fp_neg_raw(Fp<P, I>& r, const Fp<P, I>& a) {
+    uint32_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < P::N; ++i) r.v[i] = subb32(fp_kp_limb<P, K>(i), a.v[i], borrow);
+}
+// r = a + b as plain integers (no reduction; the caller keeps track of the bound)
+template <class P, bool I>
+AMDMSM_DEV void fp_add_raw(Fp<P, I>& r, const Fp<P, I>& a, const Fp<P, I>& b) {
+    uint32_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < P::N; ++i) r.v[i] = addc32(a.v[i], b.v[i], carry);
 }
 // [0, 2p) -> [0, p)
 template <class P, bool I>

@@ -208,19 +208,48 @@ AMDMSM_DEV void fp_mul_nr_lz(Fp<P, I>& r, const Fp<P, I>& x) {
         fp_neg_lz(r, t);
     }
 }
+// -(|NR| * x) as a factor for a fused product sum: 2p - x for NR = -1 (below 2p); 10p - 5x for
+// NR = -5 (below 10p: only for moduli so far below R that the sum still reduces below 2p)
+template <class P, int NR, bool I>
+AMDMSM_DEV void fp_nr_factor_lz(Fp<P, I>& r, const Fp<P, I>& x) {
+    if constexpr (NR == -1) {
+        fp_neg_raw<P, 2>(r, x);
+    } else {
+        static_assert(NR == -5, "unsupported non-residue");
+        static_assert(P::P[P::N - 1] < 0x0a000000u, "(2p*2p + 10p*2p) / R + p must stay below 2p");
+        Fp<P, I> t;
+        fp_add_raw(t, x, x);      // 2x < 4p
+        fp_add_raw(t, t, t);      // 4x < 8p
+        fp_add_raw(t, t, x);      // 5x < 10p
+        fp_neg_raw<P, 10>(r, t);
+    }
+}
+// Fq2 product on almost-reduced components.  Inline element types: schoolbook with ONE Montgomery
+// reduction per component -- c0 = x0 y0 + (NR x1) y1, c1 = x0 y1 + x1 y0 as two fused sums of two
+// products (fp_mul2_lz) -- the same 6 N^2 multiply-accumulates as Karatsuba's three full products
+// (fp2.tcc:101-114) without its six additions / subtractions and five temporaries.
 template <class P, int NR, bool I>
 AMDMSM_DEV void el_mul_lz(Fp2<P, NR, I>& r, const Fp2<P, NR, I>& x, const Fp2<P, NR, I>& y) {
-    Fp<P, I> aA, bB, s1, s2, t;
-    fp_mul_lz(aA, x.c0, y.c0);
-    fp_mul_lz(bB, x.c1, y.c1);
-    fp_add_lz(s1, x.c0, x.c1);
-    fp_add_lz(s2, y.c0, y.c1);
-    fp_mul_lz(s1, s1, s2);
-    fp_sub_lz(s1, s1, aA);
-    fp_sub_lz(s1, s1, bB);
-    fp_mul_nr_lz<P, NR, I>(t, bB);
-    fp_add_lz(r.c0, aA, t);
-    r.c1 = s1;
+    if constexpr (I) {
+        Fp<P, I> n1, c0;
+        fp_nr_factor_lz<P, NR, I>(n1, x.c1);
+        // factor bounds: n1 <= 2p (NR = -1) or 10p (NR = -5): products up to 4 p^2 / 20 p^2
+        fp_mul2_lz<P, I, (NR == -1 ? 4 : 20)>(c0, x.c0, y.c0, n1, y.c1);
+        fp_mul2_lz(r.c1, x.c0, y.c1, x.c1, y.c0);   // reads x, y before r.c1 is written (r may alias)
+        r.c0 = c0;
+    } else {
+        Fp<P, I> aA, bB, s1, s2, t;
+        fp_mul_lz(aA, x.c0, y.c0);
+        fp_mul_lz(bB, x.c1, y.c1);
+        fp_add_lz(s1, x.c0, x.c1);
+        fp_add_lz(s2, y.c0, y.c1);
+        fp_mul_lz(s1, s1, s2);
+        fp_sub_lz(s1, s1, aA);
+        fp_sub_lz(s1, s1, bB);
+        fp_mul_nr_lz<P, NR, I>(t, bB);
+        fp_add_lz(r.c0, aA, t);
+        r.c1 = s1;
+    }
 }
 template <class P, int NR, bool I>
 AMDMSM_DEV void el_sqr_lz(Fp2<P, NR, I>& r, const Fp2<P, NR, I>& x) {
@@ -235,14 +264,44 @@ AMDMSM_DEV void el_sqr_lz(Fp2<P, NR, I>& r, const Fp2<P, NR, I>& x) {
     fp_sub_lz(r.c0, s1, t);
     fp_add_lz(r.c1, ab, ab);
 }
+// r = a*b - c*d in Fq2: each component is ONE fused sum of four Fq products
+//   c0 = a0 b0 + (NR a1) b1 - c0 d0 - (NR c1) d1,   c1 = a0 b1 + a1 b0 - c0 d1 - c1 d0
+// (10 N^2 multiply-accumulates against 12 N^2 for two Fq2 products and no linear operations).
 template <class P, int NR, bool I>
 AMDMSM_DEV void el_mul_sub_mul_lz(Fp2<P, NR, I>& r, const Fp2<P, NR, I>& a, const Fp2<P, NR, I>& b, const Fp2<P, NR, I>& c,
                                   const Fp2<P, NR, I>& d) {
-    Fp2<P, NR, I> t1, t2;
-    el_mul_lz(t1, a, b);
-    el_mul_lz(t2, c, d);
-    fp_sub_lz(r.c0, t1.c0, t2.c0);
-    fp_sub_lz(r.c1, t1.c1, t2.c1);
+    if constexpr (I) {
+        // NR = -1:  c0 = a0 b0 + (2p - a1) b1 + (2p - c0) d0 + c1 d1
+        // NR = -5:  c0 = a0 b0 + (10p - 5 a1) b1 + (2p - c0) d0 + (5 c1) d1
+        Fp<P, I> na1, nc0, nc1, pc1, r0;
+        fp_nr_factor_lz<P, NR, I>(na1, a.c1);
+        fp_neg_raw<P, 2>(nc0, c.c0);
+        fp_neg_raw<P, 2>(nc1, c.c1);
+        if constexpr (NR == -1) {
+            pc1 = c.c1;
+        } else {
+            fp_add_raw(pc1, c.c1, c.c1);
+            fp_add_raw(pc1, pc1, pc1);
+            fp_add_raw(pc1, pc1, c.c1);   // 5 c1 < 10p
+        }
+        {
+            const uint32_t* const x[4] = {a.c0.v, na1.v, nc0.v, pc1.v};
+            const uint32_t* const y[4] = {b.c0.v, b.c1.v, d.c0.v, d.c1.v};
+            fp_dot_lz<P, 4, (NR == -1 ? 4 : 20)>(r0, x, y);
+        }
+        {
+            const uint32_t* const x[4] = {a.c0.v, a.c1.v, nc0.v, nc1.v};
+            const uint32_t* const y[4] = {b.c1.v, b.c0.v, d.c1.v, d.c0.v};
+            fp_dot_lz<P, 4, 4>(r.c1, x, y);
+        }
+        r.c0 = r0;
+    } else {
+        Fp2<P, NR, I> t1, t2;
+        el_mul_lz(t1, a, b);
+        el_mul_lz(t2, c, d);
+        fp_sub_lz(r.c0, t1.c0, t2.c0);
+        fp_sub_lz(r.c1, t1.c1, t2.c1);
+    }
 }
 template <class P, int NR, bool I>
 AMDMSM_DEV void el_sub_lz(Fp2<P, NR, I>& r, const Fp2<P, NR, I>& a, const Fp2<P, NR, I>& b) {

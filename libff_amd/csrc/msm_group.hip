@@ -50,8 +50,9 @@ using FR = typename GP::fr;
 #ifndef AMDMSM_BENCH_BOTH
 #define AMDMSM_BENCH_BOTH 0
 #endif
-// k_accumulate on almost-reduced coordinates (no conditional subtraction after a product,
-// fp.cuh): 2-6 % faster except where it costs registers (alt_bn128 G2: 29 % slower, so off there)
+// k_accumulate on almost-reduced coordinates (fp.cuh): no conditional subtraction after a
+// product, an Fq2 product as two fused sums of two Fq products and Y3 as one fused sum (one
+// Montgomery reduction each); 2-16 % faster on every group
 #ifndef AMDMSM_ACC_LAZY
 #define AMDMSM_ACC_LAZY 1
 #endif

@@ -15,6 +15,10 @@ CONFIGS = [("bls12_377", 1, 22), ("bls12_377", 1, 20), ("bw6_761", 1, 21), ("bls
 
 
 def main():
+    # optional arguments: curve:group:log2n ... (default: the list above)
+    global CONFIGS
+    if len(sys.argv) > 1:
+        CONFIGS = [(a.split(":")[0], int(a.split(":")[1]), int(a.split(":")[2])) for a in sys.argv[1:]]
     dev = torch.device("cuda", 0)
     eng = libff_amd.Engine(0)
     eng.set_timing(True)
