@@ -167,6 +167,22 @@ int amdmsm_multi_exp_stream_file(amdmsm_ctx *ctx, int curve, int group, const ch
                                  size_t offset_bytes, const void *scalars, size_t n,
                                  size_t chunk_points, void *out_xyz, const amdmsm_opts *opts);
 
+/* The same with compressed records -- multi_exp_stream<form_montgomery, compression_on, G, Fr>:
+ * group_write<encoding_binary, form_montgomery, compression_on> (curve_serialization.tcc:103-133)
+ * stores X only (for Fq2: c0 then c1), big-endian Montgomery limbs, with two flags in the top bits
+ * of the first byte (bit 0: lowest bit of Y.c0's Montgomery representation, bit 1: zero); the
+ * device recovers Y = sqrt(X^3 + b) (curve_utils.tcc:34-47; Tonelli-Shanks for bls12_377's Fq,
+ * a^((q+1)/4) otherwise; Fq2 by the norm method) and fixes its sign from the flag.  An X that is
+ * not the abscissa of a curve point makes the call fail with AMDMSM_ERR_BAD_ARG (the reference's
+ * sqrt does not terminate on such input). */
+int amdmsm_multi_exp_stream_compressed(amdmsm_ctx *ctx, int curve, int group, amdmsm_read_fn read,
+                                       void *read_ctx, const void *scalars, size_t n,
+                                       size_t chunk_points, void *out_xyz, const amdmsm_opts *opts);
+int amdmsm_multi_exp_stream_compressed_file(amdmsm_ctx *ctx, int curve, int group, const char *path,
+                                            size_t offset_bytes, const void *scalars, size_t n,
+                                            size_t chunk_points, void *out_xyz,
+                                            const amdmsm_opts *opts);
+
 /* Streaming MSM over precomputed multiples.  Replaces multi_exp_stream_with_precompute<
  * form_montgomery, compression_off, G, Fr> (multiexp_stream.hpp:29-42, multiexp_stream.tcc:
  * 193-223): the stream holds, for every base P, the amdmsm_precompute_num_digits(curve, c)
@@ -201,6 +217,11 @@ int amdmsm_import_bases_device(amdmsm_ctx *ctx, int curve, int group, const void
                                void *stream);
 int amdmsm_export_affine_device(amdmsm_ctx *ctx, int curve, int group, const void *d_src_affine,
                                 size_t n, void *d_dst_xyz, void *stream);
+/* group_read<encoding_binary, form_montgomery, compression_{off,on}> over n on-disk records that
+ * are already in HBM -> n compact affine points (curve_serialization.tcc:78-101, 134-166);
+ * *status != 0: some compressed X is not on the curve.  Synchronises. */
+int amdmsm_disk_decode_device(amdmsm_ctx *ctx, int curve, int group, const void *d_records, size_t n,
+                              int compressed, void *d_dst_affine, unsigned *status);
 int amdmsm_msm_device(amdmsm_ctx *ctx, int curve, int group, const void *d_bases_affine,
                       const void *d_scalars, size_t n, void *d_out_xyz, const amdmsm_opts *opts);
 /* The same with the table resident in HBM (288 GB hold [2^(jc)]P for 2^26 alt_bn128 G1 bases):

@@ -6,7 +6,9 @@
 // instead of by the reference's reader thread + SPSC fifo (multiexp_stream.tcc:164-191).
 // libff::multi_exp_stream_with_precompute<form_montgomery, compression_off, GroupT, FieldT>(
 // std::istream &, exponents, precompute_c) (multiexp_stream.hpp:29-42) is routed the same way to
-// amdmsm_multi_exp_stream_with_precompute.  Other Form / Comp combinations keep the reference body.
+// amdmsm_multi_exp_stream_with_precompute, and multi_exp_stream<form_montgomery, compression_on, ...>
+// (compressed records, curve_serialization.tcc:103-166) to amdmsm_multi_exp_stream_compressed, which
+// recovers Y on the device.  Other Form / Comp combinations keep the reference body.
 #ifndef LIBFF_AMD_MULTIEXP_STREAM_HPP_
 #define LIBFF_AMD_MULTIEXP_STREAM_HPP_
 
@@ -27,12 +29,15 @@ inline size_t istream_reader(void *is, void *dst, size_t bytes)
 
 template<typename GroupT, typename FieldT>
 GroupT gpu_multi_exp_stream(
-    std::istream &base_elements_in, const std::vector<FieldT> &exponents)
+    std::istream &base_elements_in,
+    const std::vector<FieldT> &exponents,
+    const bool compressed = false)
 {
     GroupT result = GroupT::zero();
     amdmsm_opts opts = {};
     opts.out_form = AMDMSM_OUT_LIBFF;
-    const int rc = amdmsm_multi_exp_stream(
+    const int rc = (compressed ? amdmsm_multi_exp_stream_compressed
+                               : amdmsm_multi_exp_stream)(
         default_context(),
         group_id<GroupT>::curve,
         group_id<GroupT>::group,
@@ -95,6 +100,15 @@ GroupT gpu_multi_exp_stream_with_precompute(
     {                                                                          \
         return libff_amd::gpu_multi_exp_stream<GROUP_T, FIELD_T>(              \
             base_elements_in, exponents);                                      \
+    }                                                                          \
+    template<>                                                                 \
+    inline GROUP_T                                                             \
+    multi_exp_stream<form_montgomery, compression_on, GROUP_T, FIELD_T>(       \
+        std::istream & base_elements_in,                                       \
+        const std::vector<FIELD_T> &exponents)                                 \
+    {                                                                          \
+        return libff_amd::gpu_multi_exp_stream<GROUP_T, FIELD_T>(              \
+            base_elements_in, exponents, true);                                \
     }                                                                          \
     template<>                                                                 \
     inline GROUP_T multi_exp_stream_with_precompute<                           \

@@ -1193,20 +1193,23 @@ namespace {
 // recs = records per scalar in the stream: 1 for multi_exp_stream; for the precompute variant the
 // num_digits multiples [2^(jc)]P of each base, consumed with window size precompute_c
 // (element_buffers_from_stream_producer, multiexp_stream.tcc:33-49).
+// compressed: the records hold X and two flag bits only (compression_on, curve_serialization.tcc:
+// 103-166); Y is recovered on the device by a square root.
 int stream_impl(amdmsm_ctx *ctx, int curve, int group, amdmsm_read_fn read, void *read_ctx, const void *scalars,
                 size_t n, size_t chunk_points, void *out_xyz, const amdmsm_opts *opts, size_t recs,
-                size_t precompute_c) {
+                size_t precompute_c, bool compressed = false) {
     if (!ctx || !read || !out_xyz || (n && !scalars)) return AMDMSM_ERR_BAD_ARG;
     const group_vtable *vt = find_vt(curve, group);
     if (!vt) return fail(ctx, AMDMSM_ERR_UNSUPPORTED, "unknown curve/group");
     const size_t xyz_bytes = (size_t)vt->el_words * 12, aff_bytes = (size_t)vt->el_words * 8 * recs;
+    const size_t rec_bytes = compressed ? aff_bytes / 2 : aff_bytes;   // bytes in the stream per scalar
     const size_t fr_bytes = (size_t)vt->fr_words * 4;
     if (chunk_points == 0) chunk_points = std::max<size_t>(((size_t)1 << 20) / recs, 1024);
     if (chunk_points > n && n) chunk_points = n;
     const size_t nchunks = n ? (n + chunk_points - 1) / chunk_points : 0;
     constexpr int NB = 2;
     void *h_stage[NB] = {}, *d_raw[NB] = {}, *d_aff[NB] = {}, *d_sc[NB] = {};
-    void *d_partials = nullptr;
+    void *d_partials = nullptr, *d_status = nullptr;
     hipStream_t streams[NB] = {};
     int rc = AMDMSM_OK;
     std::string err;
@@ -1224,6 +1227,7 @@ int stream_impl(amdmsm_ctx *ctx, int curve, int group, amdmsm_read_fn read, void
             if (streams[b]) (void)hipStreamDestroy(streams[b]);
         }
         if (d_partials) (void)hipFree(d_partials);
+        if (d_status) (void)hipFree(d_status);
         (void)amdmsm_set_pipeline_depth(ctx, old_depth);
     };
 #define TRY_S(expr)                                                                   \
@@ -1238,6 +1242,9 @@ int stream_impl(amdmsm_ctx *ctx, int curve, int group, amdmsm_read_fn read, void
     rc = amdmsm_set_pipeline_depth(ctx, NB);
     if (rc) return rc;
     TRY_S(hipMalloc(&d_partials, (nchunks + 1) * xyz_bytes));
+    TRY_S(hipMalloc(&d_status, 16));
+    TRY_S(hipMemsetAsync(d_status, 0, 16, ctx->stream));
+    TRY_S(hipStreamSynchronize(ctx->stream));
     for (int b = 0; b < NB && nchunks; ++b) {
         TRY_S(hipHostMalloc(&h_stage[b], chunk_points * aff_bytes, hipHostMallocDefault));
         TRY_S(hipMalloc(&d_raw[b], chunk_points * aff_bytes));
@@ -1253,7 +1260,7 @@ int stream_impl(amdmsm_ctx *ctx, int curve, int group, amdmsm_read_fn read, void
         const int b = (int)(k % NB);
         const size_t lo = k * chunk_points, cnt = std::min(chunk_points, n - lo);
         TRY_S(hipStreamSynchronize(streams[b]));   // staging buffer b is free again
-        const size_t want = cnt * aff_bytes;
+        const size_t want = cnt * rec_bytes;
         size_t got = 0;
         while (got < want) {
             const size_t r = read(read_ctx, (char *)h_stage[b] + got, want - got);
@@ -1267,7 +1274,11 @@ int stream_impl(amdmsm_ctx *ctx, int curve, int group, amdmsm_read_fn read, void
         TRY_S(hipMemcpyAsync(d_raw[b], h_stage[b], want, hipMemcpyHostToDevice, streams[b]));
         TRY_S(hipMemcpyAsync(d_sc[b], (const char *)scalars + lo * fr_bytes, cnt * fr_bytes, hipMemcpyHostToDevice,
                              streams[b]));
-        vt->disk_decode(streams[b], (const uint32_t *)d_raw[b], cnt * recs, (uint32_t *)d_aff[b]);
+        if (compressed)
+            vt->disk_decode_compressed(streams[b], (const uint32_t *)d_raw[b], cnt * recs, (uint32_t *)d_aff[b],
+                                       (uint32_t *)d_status);
+        else
+            vt->disk_decode(streams[b], (const uint32_t *)d_raw[b], cnt * recs, (uint32_t *)d_aff[b]);
         o.stream = streams[b];
         if (precompute_c)
             rc = amdmsm_msm_precomputed_device(ctx, curve, group, d_aff[b], d_sc[b], cnt, precompute_c, recs,
@@ -1282,6 +1293,13 @@ int stream_impl(amdmsm_ctx *ctx, int curve, int group, amdmsm_read_fn read, void
     TRY_S(hipDeviceSynchronize());
     vt->sum_points(ctx->stream, (const uint32_t *)d_partials, (int)nchunks, final_form,
                    (uint32_t *)((char *)d_partials + nchunks * xyz_bytes));
+    unsigned status = 0;
+    TRY_S(hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
+    TRY_S(hipStreamSynchronize(ctx->stream));
+    if (status) {   // some X is not the abscissa of a curve point: no result (the reference's sqrt would not return)
+        cleanup();
+        return fail(ctx, AMDMSM_ERR_BAD_ARG, "compressed base element is not on the curve");
+    }
     TRY_S(hipMemcpyAsync(out_xyz, (char *)d_partials + nchunks * xyz_bytes, xyz_bytes, hipMemcpyDeviceToHost, ctx->stream));
     TRY_S(hipStreamSynchronize(ctx->stream));
     cleanup();
@@ -1293,7 +1311,7 @@ size_t file_reader(void *fp, void *dst, size_t bytes) { return fread(dst, 1, byt
 
 int stream_file_impl(amdmsm_ctx *ctx, int curve, int group, const char *path, size_t offset_bytes, const void *scalars,
                      size_t n, size_t chunk_points, void *out_xyz, const amdmsm_opts *opts, size_t recs,
-                     size_t precompute_c) {
+                     size_t precompute_c, bool compressed = false) {
     if (!ctx || !path) return AMDMSM_ERR_BAD_ARG;
     FILE *fp = fopen(path, "rb");
     if (!fp) return fail(ctx, AMDMSM_ERR_BAD_ARG, std::string("cannot open ") + path);
@@ -1302,7 +1320,7 @@ int stream_file_impl(amdmsm_ctx *ctx, int curve, int group, const char *path, si
         return fail(ctx, AMDMSM_ERR_BAD_ARG, "seek failed");
     }
     const int rc = stream_impl(ctx, curve, group, file_reader, fp, scalars, n, chunk_points, out_xyz, opts, recs,
-                               precompute_c);
+                               precompute_c, compressed);
     fclose(fp);
     return rc;
 }
@@ -1320,6 +1338,44 @@ int amdmsm_multi_exp_stream_file(amdmsm_ctx *ctx, int curve, int group, const ch
                                  const void *scalars, size_t n, size_t chunk_points, void *out_xyz,
                                  const amdmsm_opts *opts) {
     return stream_file_impl(ctx, curve, group, path, offset_bytes, scalars, n, chunk_points, out_xyz, opts, 1, 0);
+}
+
+// multi_exp_stream<form_montgomery, compression_on, G, Fr> (multiexp_stream.hpp:25-27 with
+// Comp = compression_on; records of curve_serialization.tcc:103-133)
+int amdmsm_multi_exp_stream_compressed(amdmsm_ctx *ctx, int curve, int group, amdmsm_read_fn read, void *read_ctx,
+                                       const void *scalars, size_t n, size_t chunk_points, void *out_xyz,
+                                       const amdmsm_opts *opts) {
+    return stream_impl(ctx, curve, group, read, read_ctx, scalars, n, chunk_points, out_xyz, opts, 1, 0, true);
+}
+
+int amdmsm_multi_exp_stream_compressed_file(amdmsm_ctx *ctx, int curve, int group, const char *path, size_t offset_bytes,
+                                            const void *scalars, size_t n, size_t chunk_points, void *out_xyz,
+                                            const amdmsm_opts *opts) {
+    return stream_file_impl(ctx, curve, group, path, offset_bytes, scalars, n, chunk_points, out_xyz, opts, 1, 0, true);
+}
+
+// group_read<encoding_binary, form_montgomery, Comp> over an array of records already in HBM
+// (curve_serialization.tcc:78-101 / 134-166): n compact affine points out.
+int amdmsm_disk_decode_device(amdmsm_ctx *ctx, int curve, int group, const void *d_records, size_t n, int compressed,
+                              void *d_dst_affine, unsigned *status) {
+    GET_VT(ctx, curve, group);
+    if (n && (!d_records || !d_dst_affine)) return fail(ctx, AMDMSM_ERR_BAD_ARG, "null pointer");
+    hipStream_t st = ctx->stream;
+    unsigned hs = 0;
+    if (compressed) {
+        int rc = ensure_buf(ctx, ctx->hb_stats, 16);
+        if (rc) return rc;
+        HIP_TRY(ctx, hipMemsetAsync(ctx->hb_stats.p, 0, 16, st));
+        vt->disk_decode_compressed(st, (const uint32_t *)d_records, n, (uint32_t *)d_dst_affine, (uint32_t *)ctx->hb_stats.p);
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipMemcpyAsync(&hs, ctx->hb_stats.p, 4, hipMemcpyDeviceToHost, st));
+    } else {
+        vt->disk_decode(st, (const uint32_t *)d_records, n, (uint32_t *)d_dst_affine);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (status) *status = hs;
+    return AMDMSM_OK;
 }
 
 // multi_exp_stream_with_precompute (multiexp_stream.hpp:29-42, multiexp_stream.tcc:193-223): the

@@ -497,6 +497,86 @@ AMDMSM_DEV void fp_inv(Fp<P, I>& r, const Fp<P, I>& a) {
     r = acc;
 }
 
+// a^e for the N-word constant exponent E (scanned MSB first; the limb is selected without a
+// runtime-indexed private array)
+template <class P, bool I>
+AMDMSM_DEV void fp_pow_words(Fp<P, I>& r, const Fp<P, I>& a, const uint32_t (&e)[P::N]) {
+    constexpr int N = P::N;
+    Fp<P, I> acc;
+    fp_set_one(acc);
+    bool started = false;
+    for (int i = N * 32 - 1; i >= 0; --i) {
+        const int li = i >> 5;
+        uint32_t w = 0;
+#pragma unroll
+        for (int k = 0; k < N; ++k) w = (li == k) ? e[k] : w;
+        if (started) fp_sqr(acc, acc);
+        if ((w >> (i & 31)) & 1u) {
+            fp_mul(acc, acc, a);
+            started = true;
+        }
+    }
+    r = acc;
+}
+
+// Square root (Fp_model::sqrt, fp.tcc:729-776).  p = 3 mod 4: a^((p+1)/4); otherwise
+// Tonelli-Shanks with p - 1 = 2^s t, the same constants the reference keeps per field
+// (s, (t-1)/2, nqr^t).  Returns false when a is not a square (the reference's loop would not
+// terminate there).  Either root may come back; callers fix the sign themselves.
+template <class P, bool I>
+AMDMSM_DEV bool fp_sqrt(Fp<P, I>& r, const Fp<P, I>& a) {
+    if (fp_is_zero(a)) {
+        fp_set_zero(r);
+        return true;
+    }
+    if constexpr (P::SQRT_S == 1) {
+        Fp<P, I> x, c;
+        fp_pow_words(x, a, P::SQRT_EXP);
+        fp_sqr(c, x);
+        r = x;
+        return fp_eq(c, a);
+    } else {
+        Fp<P, I> one, w, x, b, z, b2;
+        fp_set_one(one);
+        fp_pow_words(w, a, P::SQRT_EXP);   // a^((t-1)/2)
+        fp_mul(x, a, w);                    // a^((t+1)/2)
+        fp_mul(b, x, w);                    // a^t
+#pragma unroll
+        for (int i = 0; i < P::N; ++i) z.v[i] = P::NQR_TO_T[i];
+        int v = P::SQRT_S;
+        while (!fp_eq(b, one)) {
+            int m = 0;
+            b2 = b;
+            while (!fp_eq(b2, one) && m < v) {   // least m with b^(2^m) == 1
+                fp_sqr(b2, b2);
+                ++m;
+            }
+            if (m >= v) return false;            // a is not a square
+            w = z;
+            for (int j = 0; j < v - m - 1; ++j) fp_sqr(w, w);
+            fp_sqr(z, w);
+            fp_mul(b, b, z);
+            fp_mul(x, x, w);
+            v = m;
+        }
+        r = x;
+        return true;
+    }
+}
+
+// a / 2
+template <class P, bool I>
+AMDMSM_DEV void fp_half(Fp<P, I>& r, const Fp<P, I>& a) {
+    const uint32_t mask = 0u - (a.v[0] & 1u);   // odd: add p first (p is odd)
+    uint32_t t[P::N + 1];
+    uint32_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < P::N; ++i) t[i] = addc32(a.v[i], P::P[i] & mask, carry);
+    t[P::N] = carry;
+#pragma unroll
+    for (int i = 0; i < P::N; ++i) r.v[i] = (t[i] >> 1) | (t[i + 1] << 31);
+}
+
 template <class P, bool I>
 AMDMSM_DEV void fp_load(Fp<P, I>& r, const uint32_t* __restrict__ p) {
     constexpr int N = P::N;

@@ -159,6 +159,51 @@ template <class P, int NR, bool I> AMDMSM_DEV void el_inv(Fp2<P, NR, I>& r, cons
     fp_mul(t2, x.c1, t1);
     fp_neg(r.c1, t2);
 }
+// square roots of coordinate-field elements (curve_point_y_at_x, curve_utils.tcc:34-47)
+template <class P, bool I> AMDMSM_DEV bool el_sqrt(Fp<P, I>& r, const Fp<P, I>& a) { return fp_sqrt(r, a); }
+// Fq2: with N = a0^2 - NR a1^2 (the norm) and s = sqrt(N), x0^2 = (a0 +- s) / 2 and x1 = a1 / (2 x0)
+// ("complex method"; the reference runs Tonelli-Shanks over Fq2, fp2.tcc:176-222 -- both give
+// a root of the same element, the caller fixes the sign).  False when a is not a square in Fq2.
+template <class P, int NR, bool I> AMDMSM_DEV bool el_sqrt(Fp2<P, NR, I>& r, const Fp2<P, NR, I>& a) {
+    Fp<P, I> t, s, d, x0, x1;
+    if (fp_is_zero(a.c1)) {
+        if (fp_sqrt(t, a.c0)) {          // a0 is a square in Fq
+            r.c0 = t;
+            fp_set_zero(r.c1);
+            return true;
+        }
+        // (y u)^2 = NR y^2 = a0  ->  y = sqrt(a0 / NR)
+        Fp<P, I> nr, one;
+        fp_set_one(one);
+        fp_mul_nr<P, NR, I>(nr, one);
+        fp_inv(nr, nr);
+        fp_mul(t, a.c0, nr);
+        if (!fp_sqrt(x1, t)) return false;
+        fp_set_zero(r.c0);
+        r.c1 = x1;
+        return true;
+    }
+    fp_sqr(t, a.c0);
+    fp_sqr(s, a.c1);
+    fp_mul_nr<P, NR, I>(d, s);
+    fp_sub(t, t, d);                      // norm
+    if (!fp_sqrt(s, t)) return false;
+    fp_add(d, a.c0, s);
+    fp_half(d, d);
+    if (!fp_sqrt(x0, d)) {
+        fp_sub(d, a.c0, s);
+        fp_half(d, d);
+        if (!fp_sqrt(x0, d)) return false;
+    }
+    fp_dbl(t, x0);
+    fp_inv(t, t);
+    fp_mul(x1, a.c1, t);
+    r.c0 = x0;
+    r.c1 = x1;
+    Fp2<P, NR, I> chk;
+    el_sqr(chk, r);
+    return el_eq(chk, a);
+}
 template <class P, int NR, bool I> AMDMSM_DEV void el_load(Fp2<P, NR, I>& r, const uint32_t* p) {
     fp_load(r.c0, p);
     fp_load(r.c1, p + P::N);

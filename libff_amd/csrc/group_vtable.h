@@ -119,6 +119,9 @@ struct group_vtable {
 
     // libff on-disk base records (binary, Montgomery, uncompressed) -> compact affine
     void (*disk_decode)(hipStream_t, const uint32_t* src, size_t n, uint32_t* dst_affine);
+    // the compressed form of the same records (X with two flag bits, Y by square root);
+    // *status |= 2 where X is not the abscissa of a curve point
+    void (*disk_decode_compressed)(hipStream_t, const uint32_t* src, size_t n, uint32_t* dst_affine, uint32_t* status);
     // fixed-base batch exponentiation: out[i] = (coeff *) scalars[i] * g via a window table
     // (get_window_table / windowed_exp / batch_exp[_with_coeff], multiexp.tcc:809-947);
     // gouter: outerc points, table: outerc * 2^window points, outerc = ceil(scalar_size / window)

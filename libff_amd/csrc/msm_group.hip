@@ -1330,6 +1330,41 @@ __global__ void __launch_bounds__(TPB) k_disk_decode(const uint32_t* __restrict_
     store_aff(dst + i * AFFW, a);
 }
 
+// Compressed records (group_element_codec<encoding_binary, form_montgomery, compression_on>,
+// curve_serialization.tcc:103-166): X only -- for Fq2 its component c0 first, then c1 -- each
+// component big-endian, with two flag bits in the top of the first component's highest limb
+// (field_serialization.tcc:186-266: FLAG_SHIFT = 62): bit 0 = lowest bit of Y.c0's Montgomery
+// representation, bit 1 = the element is zero.  Y = sqrt(X^3 + b) (curve_point_y_at_x,
+// curve_utils.tcc:34-47), negated when its low bit disagrees with the flag.  status |= 2 where
+// X^3 + b has no square root (the reference's sqrt does not terminate on such input).
+AMDMSM_DEV const Fp<FQ, false>& coord_c0(const Fp<FQ, false>& a) { return a; }
+template <int NR>
+AMDMSM_DEV const Fp<FQ, false>& coord_c0(const Fp2<FQ, NR, false>& a) { return a.c0; }
+
+__global__ void __launch_bounds__(64) k_disk_decode_compressed(const uint32_t* __restrict__ src, size_t n,
+                                                                 uint32_t* __restrict__ dst, uint32_t* __restrict__ status) {
+    const size_t i = gtid();
+    if (i >= n) return;
+    const uint32_t* q = src + i * EW;
+    const uint32_t flags = bswap32(q[0]) >> 30;
+    Aff<E> a;
+    load_coord_disk(a.x, q);
+    reinterpret_cast<uint32_t*>(&a.x)[FQ::N - 1] &= 0x3fffffffu;   // top limb of component 0 carries the flags
+    if (flags & 2u) {
+        el_zero(a.x);
+        el_zero(a.y);
+    } else {
+        E y2, b;
+        el_sqr(y2, a.x);
+        el_mul(y2, y2, a.x);
+        el_set_words(b, GP::COEFF_B);
+        el_add(y2, y2, b);
+        if (!el_sqrt(a.y, y2)) atomicOr(status, 2u);
+        if ((coord_c0(a.y).v[0] & 1u) != (flags & 1u)) el_neg(a.y, a.y);
+    }
+    store_aff(dst + i * AFFW, a);
+}
+
 // ------------------------------------------------- fixed-base exponentiation
 // batch_exp / batch_exp_with_coeff (multiexp.tcc:874-947): res[i] = v[i] * g through a window
 // table powers_of_g[outer][inner] = inner * 2^(outer*window) * g (get_window_table,
@@ -1766,6 +1801,10 @@ void l_disk_decode(hipStream_t st, const uint32_t* src, size_t n, uint32_t* dst)
     if (!n) return;
     hipLaunchKernelGGL(k_disk_decode, dim3(blocks_for(n)), dim3(TPB), 0, st, src, n, dst);
 }
+void l_disk_decode_compressed(hipStream_t st, const uint32_t* src, size_t n, uint32_t* dst, uint32_t* status) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_disk_decode_compressed, dim3(blocks_for(n, 64)), dim3(64), 0, st, src, n, dst, status);
+}
 // table: outerc * 2^window points, gouter: outerc points
 void l_fixed_base_exp(hipStream_t st, const uint32_t* g_xyz, int scalar_size, int window, const uint32_t* scalars, size_t n,
                       int mont, const uint32_t* coeff, int form, uint32_t* gouter, uint32_t* table, uint32_t* out) {
@@ -1821,7 +1860,7 @@ void l_madd_bench(hipStream_t st, const uint32_t* pts, uint32_t* out, size_t nth
 const group_vtable g_vt = {
     GP::CURVE, GP::GROUP, FRW, EW, FQ::N, FR::BITS, GP::LIBFF_PROJECTIVE ? 1 : 0, FR::R,
     l_import_bases, l_precompute_table, l_count, l_scatter, l_scalar_stats, l_sort, l_accumulate, l_accumulate_resident_lanes, l_accumulate_fixup, l_reduce_segments, l_sum_butterfly, l_horner, l_sum_points,
-    l_gen_bases_seq, l_export_affine, l_ffi_decode_points, l_ffi_decode_scalars, l_ffi_encode_point, l_disk_decode, l_fixed_base_exp, l_field_op, l_group_op, l_digits, l_mul_bench, l_madd_bench,
+    l_gen_bases_seq, l_export_affine, l_ffi_decode_points, l_ffi_decode_scalars, l_ffi_encode_point, l_disk_decode, l_disk_decode_compressed, l_fixed_base_exp, l_field_op, l_group_op, l_digits, l_mul_bench, l_madd_bench,
 };
 
 }  // namespace

@@ -45,6 +45,7 @@ EXPORTED_SYMBOLS = [
     "amdmsm_multi_exp_multi", "amdmsm_msm_device_multi", "amdmsm_register_bases", "amdmsm_unregister_bases",
     "amdmsm_invalidate_bases",
     "amdmsm_batch_to_special", "amdmsm_batch_exp", "amdmsm_multi_exp_stream", "amdmsm_multi_exp_stream_file",
+    "amdmsm_multi_exp_stream_compressed", "amdmsm_multi_exp_stream_compressed_file", "amdmsm_disk_decode_device",
     "amdmsm_precompute_num_digits", "amdmsm_multi_exp_stream_with_precompute",
     "amdmsm_multi_exp_stream_with_precompute_file", "amdmsm_precompute_bases_device",
     "amdmsm_msm_precomputed_device", "amdmsm_import_bases_device", "amdmsm_export_affine_device",
@@ -308,6 +309,42 @@ class Engine:
                                                    _np_ptr(out), ctypes.byref(o))
         self._check(rc, "amdmsm_multi_exp_stream_file")
         return out
+
+    def multi_exp_stream_compressed_file(self, curve, group, path, scalars, offset_bytes=0, chunk_points=0,
+                                         out_form=OUT_AFFINE, scalars_plain=False):
+        """libff::multi_exp_stream<form_montgomery, compression_on>: ``path`` holds compressed records
+        (curve_serialization.tcc:103-133); Y is recovered on the device."""
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint64)
+        s = sizes(curve, group)
+        out = np.zeros(s["g_bytes"] // 8, dtype=np.uint64)
+        o = self._opts(out_form=out_form, scalars_plain=scalars_plain)
+        rc = self.lib.amdmsm_multi_exp_stream_compressed_file(
+            self.h, curve, group, path.encode(), ctypes.c_size_t(offset_bytes),
+            _np_ptr(scalars) if scalars.shape[0] else None, ctypes.c_size_t(scalars.shape[0]),
+            ctypes.c_size_t(chunk_points), _np_ptr(out), ctypes.byref(o))
+        self._check(rc, "amdmsm_multi_exp_stream_compressed_file")
+        return out
+
+    def disk_decode(self, curve, group, records, n, compressed):
+        """group_read<encoding_binary, form_montgomery, compression_{off,on}> of ``n`` records (uint8 array)
+        on the device -> (special-form (X, Y, Z) records, status)."""
+        records = np.ascontiguousarray(records, dtype=np.uint8)
+        s = sizes(curve, group)
+        d_rec, d_aff, d_xyz = self.malloc(max(16, records.nbytes)), self.malloc(max(16, n * s["affine_bytes"])), \
+            self.malloc(max(16, n * s["g_bytes"]))
+        try:
+            self.h2d(d_rec, records)
+            st = ctypes.c_uint(0)
+            self._check(self.lib.amdmsm_disk_decode_device(self.h, curve, group, d_rec, ctypes.c_size_t(n), int(compressed),
+                                                           d_aff, ctypes.byref(st)), "amdmsm_disk_decode_device")
+            self.export_affine_device(curve, group, d_aff.value, n, d_xyz.value)
+            out = np.zeros((n, s["g_bytes"] // 8), dtype=np.uint64)
+            self.synchronize()
+            self.d2h(out, d_xyz)
+            return out, st.value
+        finally:
+            for p in (d_rec, d_aff, d_xyz):
+                self.free(p)
 
     def multi_exp_stream_with_precompute_file(self, curve, group, path, scalars, precompute_c, offset_bytes=0,
                                               chunk_points=0, out_form=OUT_AFFINE, scalars_plain=False):

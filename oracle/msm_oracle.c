@@ -1266,6 +1266,198 @@ int orc_disk_write(int curve, int group, size_t n, const uint64_t *elems, uint8_
     return 0;
 }
 
+/* ------------------------------------------------- compressed records */
+static void fp_pow(const orc_field *f, uint64_t *r, const uint64_t *a, const uint64_t *e, int en)
+{
+    uint64_t acc[MAXN], base[MAXN];
+    memcpy(acc, f->r, (size_t)f->n * 8);
+    memcpy(base, a, (size_t)f->n * 8);
+    for (size_t i = bi_num_bits(e, en); i-- > 0;) {
+        fp_sqr(f, acc, acc);
+        if (bi_test_bit(e, en, i)) fp_mul(f, acc, acc, base);
+    }
+    memcpy(r, acc, (size_t)f->n * 8);
+}
+/* Fp_model::sqrt, fp.tcc:763-810 (Tonelli-Shanks on p - 1 = 2^s t).  The reference keeps s,
+ * (t-1)/2 and nqr^t as per-field constants (e.g. bls12_377_init.cpp:119-126); here they are derived
+ * from p, with the smallest non-residue -- a different non-residue can only change WHICH of the
+ * two roots comes back, and every caller fixes the sign.  Returns 0 when a is not a square (the
+ * reference's loop does not terminate there). */
+static int fp_sqrt(const orc_field *f, uint64_t *r, const uint64_t *a)
+{
+    const int n = f->n;
+    uint64_t one_plain[MAXN] = {1}, pm1[MAXN], t[MAXN], e[MAXN], w[MAXN], x[MAXN], b[MAXN], z[MAXN], b2[MAXN], g[MAXN];
+    if (bi_is_zero(a, n)) {
+        memset(r, 0, (size_t)n * 8);
+        return 1;
+    }
+    bi_sub(pm1, f->p, one_plain, n);
+    size_t s = 0;
+    while (!bi_test_bit(pm1, n, s)) ++s;
+    /* t = (p - 1) >> s, e = (t - 1) / 2 = (p - 1) >> (s + 1) */
+    memset(t, 0, sizeof t);
+    memset(e, 0, sizeof e);
+    for (size_t i = 0; i + s < (size_t)n * 64; ++i) {
+        if (bi_test_bit(pm1, n, i + s)) t[i / 64] |= 1ull << (i % 64);
+        if (i + s + 1 < (size_t)n * 64 && bi_test_bit(pm1, n, i + s + 1)) e[i / 64] |= 1ull << (i % 64);
+    }
+    /* z = nqr^t: smallest g with g^((p-1)/2) == -1 */
+    uint64_t half[MAXN], minus_one[MAXN];
+    memset(half, 0, sizeof half);
+    for (size_t i = 0; i + 1 < (size_t)n * 64; ++i)
+        if (bi_test_bit(pm1, n, i + 1)) half[i / 64] |= 1ull << (i % 64);
+    fp_neg(f, minus_one, f->r);
+    for (uint64_t cand = 2;; ++cand) {
+        uint64_t cp[MAXN] = {cand}, chk[MAXN];
+        fp_to_mont(f, g, cp);
+        fp_pow(f, chk, g, half, n);
+        if (bi_eq(chk, minus_one, n)) break;
+    }
+    fp_pow(f, z, g, t, n);
+    fp_pow(f, w, a, e, n);
+    fp_mul(f, x, a, w);
+    fp_mul(f, b, x, w);
+    size_t v = s;
+    while (!bi_eq(b, f->r, n)) {
+        size_t m = 0;
+        memcpy(b2, b, (size_t)n * 8);
+        while (!bi_eq(b2, f->r, n) && m < v) {
+            fp_sqr(f, b2, b2);
+            ++m;
+        }
+        if (m >= v) return 0;
+        memcpy(w, z, (size_t)n * 8);
+        for (size_t j = 0; j + m + 1 < v; ++j) fp_sqr(f, w, w);
+        fp_sqr(f, z, w);
+        fp_mul(f, b, b, z);
+        fp_mul(f, x, x, w);
+        v = m;
+    }
+    memcpy(r, x, (size_t)n * 8);
+    return 1;
+}
+static void fp_half(const orc_field *f, uint64_t *r, const uint64_t *a)
+{
+    uint64_t t[MAXN + 1];
+    uint64_t carry = 0;
+    if (a[0] & 1) carry = bi_add(t, a, f->p, f->n);
+    else memcpy(t, a, (size_t)f->n * 8);
+    t[f->n] = carry;
+    for (int i = 0; i < f->n; ++i) r[i] = (t[i] >> 1) | (t[i + 1] << 63);
+}
+/* square root in the coordinate field.  Fq2: the reference runs Tonelli-Shanks over Fq2
+ * (fp2.tcc:176-222); this restatement uses the norm ("complex") method -- with N = a0^2 - nr a1^2,
+ * s = sqrt(N): x0^2 = (a0 +- s) / 2, x1 = a1 / (2 x0) -- which returns a root of the same element;
+ * the compressed-point decoder fixes the sign from its flag bit either way. */
+static int el_sqrt(const ctx_t *c, uint64_t *r, const uint64_t *a)
+{
+    if (c->deg == 1) return fp_sqrt(c->f, r, a);
+    const orc_field *f = c->f;
+    const int n = c->n;
+    uint64_t t[MAXN], s[MAXN], d[MAXN], x0[MAXN], x1[MAXN], chk[MAXE];
+    if (bi_is_zero(a + n, n)) {
+        if (fp_sqrt(f, t, a)) {
+            memcpy(r, t, (size_t)n * 8);
+            memset(r + n, 0, (size_t)n * 8);
+            return 1;
+        }
+        fp_inv(f, t, c->g->nr);
+        fp_mul(f, t, a, t);
+        if (!fp_sqrt(f, x1, t)) return 0;
+        memset(r, 0, (size_t)n * 8);
+        memcpy(r + n, x1, (size_t)n * 8);
+        return 1;
+    }
+    fp_sqr(f, t, a);
+    fp_sqr(f, s, a + n);
+    fp_mul(f, d, c->g->nr, s);
+    fp_sub(f, t, t, d);
+    if (!fp_sqrt(f, s, t)) return 0;
+    fp_add(f, d, a, s);
+    fp_half(f, d, d);
+    if (!fp_sqrt(f, x0, d)) {
+        fp_sub(f, d, a, s);
+        fp_half(f, d, d);
+        if (!fp_sqrt(f, x0, d)) return 0;
+    }
+    fp_add(f, t, x0, x0);
+    fp_inv(f, t, t);
+    fp_mul(f, x1, a + n, t);
+    memcpy(r, x0, (size_t)n * 8);
+    memcpy(r + n, x1, (size_t)n * 8);
+    el_sqr(c, chk, r);
+    return el_eq(c, chk, a);
+}
+/* group_element_codec<encoding_binary, form_montgomery, compression_on>::write,
+ * curve_serialization.tcc:110-133 over field_write_with_flags (field_serialization.tcc:148-161,
+ * 224-241): X only, components c0 (with the two flag bits in the top of its highest limb), c1,
+ * each the byte-reversed Montgomery bigint; flags: bit 0 = Y.c0.mont_repr.data[0] & 1, bit 1 = zero. */
+int orc_disk_write_compressed(int curve, int group, size_t n, const uint64_t *elems, uint8_t *out)
+{
+    const orc_group *g = find_group(curve, group);
+    if (!g) return -2;
+    ctx_t cc = mkctx(g);
+    const ctx_t *c = &cc;
+    const int gl = GLIMBS(c);
+    const size_t cb = (size_t)c->n * 8;
+    for (size_t i = 0; i < n; ++i) {
+        uint64_t aff[MAXG], x[MAXE];
+        uint64_t flags;
+        if (g_is_zero(c, elems + i * gl)) {
+            el_cpy(c, x, GX(elems + i * gl));   /* "Use Montgomery encoding": the stored X as it stands */
+            flags = 2;
+        } else {
+            g_to_affine(c, aff, elems + i * gl);
+            el_cpy(c, x, GX(aff));
+            flags = GY(aff)[0] & 1;
+        }
+        x[c->n - 1] |= flags << 62;
+        for (int k = 0; k < c->deg; ++k) {
+            const uint8_t *src = (const uint8_t *)(x + k * c->n);
+            uint8_t *dst = out + (i * (size_t)c->deg + (size_t)k) * cb;
+            for (size_t b = 0; b < cb; ++b) dst[b] = src[cb - 1 - b];
+        }
+    }
+    return 0;
+}
+/* ...::read, curve_serialization.tcc:134-166 with curve_point_y_at_x (curve_utils.tcc:34-47);
+ * returns the number of records whose X is not the abscissa of a curve point (0 = all decoded). */
+int orc_disk_read_compressed(int curve, int group, size_t n, const uint8_t *in, uint64_t *out)
+{
+    const orc_group *g = find_group(curve, group);
+    if (!g) return -2;
+    ctx_t cc = mkctx(g);
+    const ctx_t *c = &cc;
+    const int gl = GLIMBS(c);
+    const size_t cb = (size_t)c->n * 8;
+    int bad = 0;
+    for (size_t i = 0; i < n; ++i) {
+        uint64_t *p = out + i * gl;
+        for (int k = 0; k < c->deg; ++k) {
+            uint8_t *dst = (uint8_t *)(GX(p) + k * c->n);
+            const uint8_t *src = in + (i * (size_t)c->deg + (size_t)k) * cb;
+            for (size_t b = 0; b < cb; ++b) dst[b] = src[cb - 1 - b];
+        }
+        const uint64_t flags = GX(p)[c->n - 1] >> 62;
+        GX(p)[c->n - 1] &= (1ull << 62) - 1;
+        if (flags & 2) {
+            g_zero(c, p);
+            continue;
+        }
+        uint64_t y2[MAXE];
+        el_sqr(c, y2, GX(p));
+        el_mul(c, y2, y2, GX(p));
+        el_add(c, y2, y2, g->coeff_b);
+        if (!el_sqrt(c, GY(p), y2)) {
+            ++bad;
+            continue;
+        }
+        if ((GY(p)[0] & 1) != (flags & 1)) el_neg(c, GY(p), GY(p));
+        el_one(c, GZ(p));
+    }
+    return bad;
+}
+
 /* ------------------------------------------------- precomputed multiples */
 /* entries_per_base_element, profile_multiexp.cpp:126 == num_digits, multiexp_stream.tcc:205 */
 size_t orc_precompute_num_digits(int curve, size_t c)

@@ -68,6 +68,10 @@ int orc_batch_exp(int curve, int group, size_t scalar_size, size_t window, const
 
 /* n elements -> libff's binary / Montgomery / uncompressed records (2 * coord bytes each) */
 int orc_disk_write(int curve, int group, size_t n, const uint64_t *elems, uint8_t *out);
+/* compression_on records (curve_serialization.tcc:103-166): n * coordinate bytes; read returns the
+ * number of records that are not on the curve */
+int orc_disk_write_compressed(int curve, int group, size_t n, const uint64_t *elems, uint8_t *out);
+int orc_disk_read_compressed(int curve, int group, size_t n, const uint8_t *in, uint64_t *out);
 
 /* precomputed multiples [2^(kc)]P (profile_multiexp.cpp:120-150) and the single-bucket-set MSM
  * over them (multi_exp_stream_with_precompute, multiexp_stream.tcc:124-162, 193-223) */

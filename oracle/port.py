@@ -213,6 +213,25 @@ def disk_write(curve, group, elems):
     return out
 
 
+def disk_write_compressed(curve, group, elems):
+    """group_write<encoding_binary, form_montgomery, compression_on> records (curve_serialization.tcc:110-133)."""
+    s = sizes(curve, group)
+    elems = _u64(elems)
+    out = np.zeros(elems.shape[0] * s["coord_bytes"], dtype=np.uint8)
+    assert lib().orc_disk_write_compressed(curve, group, ctypes.c_size_t(elems.shape[0]), _p(elems), _p(out)) == 0
+    return out
+
+
+def disk_read_compressed(curve, group, data, n):
+    """group_read<..., compression_on> (curve_serialization.tcc:134-166): (elements, records not on the curve)."""
+    s = sizes(curve, group)
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    out = np.zeros((n, s["g_bytes"] // 8), dtype=np.uint64)
+    bad = lib().orc_disk_read_compressed(curve, group, ctypes.c_size_t(n), _p(data), _p(out))
+    assert bad >= 0
+    return out, bad
+
+
 def bdlo12_signed_optimal_c(n):
     return int(lib().orc_bdlo12_signed_optimal_c(ctypes.c_size_t(n)))
 

@@ -83,6 +83,15 @@ template<typename G, typename Fr> void check_group(const char *name, const std::
             const G rs = multi_exp_stream<form_montgomery, compression_off, G, Fr>(ss, scalars);
             ok = ok && (expect == rs);
         }
+        // the same with compressed records: Y comes back from a device square root
+        {
+            std::stringstream ss(std::ios_base::in | std::ios_base::out | std::ios_base::binary);
+            for (const G &b : special) {
+                group_write<encoding_binary, form_montgomery, compression_on>(b, ss);
+            }
+            const G rc = multi_exp_stream<form_montgomery, compression_on, G, Fr>(ss, scalars);
+            ok = ok && (expect == rc);
+        }
         // precomputed multiples, laid out as create_precompute_file_for_config does
         // (profile_multiexp.cpp:120-150); c = 7 leaves spare bits in the top digit of every Fr
         // here, so the routed multi_exp_stream_with_precompute must return the plain sum

@@ -464,6 +464,55 @@ def test_multi_exp_stream_from_file(engine, port, name, curve, group, tmp_path):
 
 
 @pytest.mark.parametrize("name,curve,group", GROUPS)
+def test_compressed_records_decode_and_stream(engine, port, name, curve, group, tmp_path):
+    """multi_exp_stream<form_montgomery, compression_on> (curve_serialization.tcc:103-166): the device
+    recovers Y by a square root (Tonelli-Shanks for bls12_377's Fq, a^((q+1)/4) otherwise, the norm
+    method in Fq2) and fixes its sign from the flag.  Decoded points == what the reference itself
+    reads back from the same bytes (fixtures), streamed MSM == oracle MSM over those points, and a
+    record whose X has no point above it fails the call."""
+    g = golden()
+    for key, want_key in (("disk_bytes_compressed", "disk_compressed_decoded"), ("curve_points_compressed", "curve_points")):
+        want = g[f"{name}/{want_key}"]
+        got, status = engine.disk_decode(curve, group, g[f"{name}/{key}"], want.shape[0], compressed=True)
+        assert status == 0 and (got == want).all(), key
+    # uncompressed records through the same entry
+    got, status = engine.disk_decode(curve, group, g[f"{name}/disk_bytes"], 6, compressed=False)
+    assert status == 0 and (got == g[f"{name}/disk_compressed_decoded"]).all()
+    # a few hundred points: multiples of the generator, their negatives, zeros in between
+    n = 400 if group == 1 and curve != 2 else 150
+    pts = port.bases_seq(curve, group, n, first=9)
+    neg = port.group_op(curve, group, 3, pts[1])
+    pts[1] = neg
+    _, zero = port.group_consts(curve, group)
+    pts[5] = zero
+    pts[n - 1] = zero
+    sc = port.scalars_sha512(curve, 321, n)
+    rec = port.disk_write_compressed(curve, group, pts)
+    path = tmp_path / "bases_compressed.bin"
+    path.write_bytes(b"\x55" * 24 + rec.tobytes())
+    want = port.multi_exp(curve, group, pts, sc, port.BDLO12_SIGNED, 0)
+    got = engine.multi_exp_stream_compressed_file(curve, group, str(path), sc, offset_bytes=24, chunk_points=64)
+    assert (got == want).all()
+    got = engine.multi_exp_stream_compressed_file(curve, group, str(path), sc, offset_bytes=24)
+    assert (got == want).all()
+    # find an X with no point above it (about every second x): the call must fail, not return a value
+    cb = port.sizes(curve, group)["coord_bytes"]
+    bad_rec = None
+    for delta in range(1, 60):
+        r2 = rec.copy()
+        r2[7 * cb + cb - 1] = (int(r2[7 * cb + cb - 1]) + delta) & 0xFF
+        if port.disk_read_compressed(curve, group, r2[7 * cb: 8 * cb], 1)[1] == 1:
+            bad_rec = r2
+            break
+    assert bad_rec is not None
+    _, status = engine.disk_decode(curve, group, bad_rec, n, compressed=True)
+    assert status != 0
+    path.write_bytes(bad_rec.tobytes())
+    with pytest.raises(libff_amd.AmdMsmError):
+        engine.multi_exp_stream_compressed_file(curve, group, str(path), sc)
+
+
+@pytest.mark.parametrize("name,curve,group", GROUPS)
 def test_precomputed_multiples_msm(engine, port, name, curve, group, tmp_path):
     """multi_exp_stream_with_precompute (multiexp_stream.tcc:193-223): the device-built table of
     [2^(kc)]P equals the oracle's, the golden results of the reference (including the window

@@ -192,6 +192,31 @@ def test_ffi_read_rejects_points_outside_the_safe_subgroup(port, name, curve, gr
 
 
 @pytest.mark.parametrize("name,curve,group", GROUPS)
+def test_compressed_records_match_reference_bytes(port, name, curve, group):
+    """group_write / group_read<encoding_binary, form_montgomery, compression_on>
+    (curve_serialization.tcc:103-166): the reference's own bytes for an affine, a zero and a
+    non-affine element and for six curve points found by scanning x, and what the reference reads
+    back from them (Y by sqrt, sign from the flag bit)."""
+    g = golden()
+    for key, src, want_key in (("disk_bytes_compressed", "disk_elems", "disk_compressed_decoded"),
+                               ("curve_points_compressed", "curve_points", "curve_points")):
+        elems = g[f"{name}/{src}"]
+        assert (port.disk_write_compressed(curve, group, elems) == g[f"{name}/{key}"]).all()
+        back, bad = port.disk_read_compressed(curve, group, g[f"{name}/{key}"], elems.shape[0])
+        assert bad == 0 and (back == g[f"{name}/{want_key}"]).all()
+    # an X with no point above it is reported, not decoded
+    rec = g[f"{name}/curve_points_compressed"].copy()
+    cb = port.sizes(curve, group)["coord_bytes"]
+    hits = 0
+    for delta in range(1, 40):
+        r2 = rec[:cb].copy()
+        r2[-1] = (int(r2[-1]) + delta) & 0xFF
+        _, bad = port.disk_read_compressed(curve, group, r2, 1)
+        hits += bad
+    assert hits > 5   # about half of all x have no square root of x^3 + b
+
+
+@pytest.mark.parametrize("name,curve,group", GROUPS)
 def test_batch_exp(port, name, curve, group):
     """get_window_table + batch_exp / batch_exp_with_coeff (multiexp.tcc:809-947)."""
     g = golden()

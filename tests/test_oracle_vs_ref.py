@@ -93,3 +93,16 @@ def test_batch_exp_matches_reference(port, ref, name, curve, group):
         assert (port.batch_exp(curve, group, bits, w, g, v) == ref.batch_exp(curve, group, bits, w, g, v)).all()
     assert (port.batch_exp(curve, group, bits, 3, g, v, coeff=v[2]) ==
             ref.batch_exp(curve, group, bits, 3, g, v, coeff=v[2])).all()
+
+
+@pytest.mark.parametrize("name,curve,group", GROUPS)
+def test_compressed_codec_vs_reference(port, ref, name, curve, group):
+    """Compressed records of 24 further curve points (other x seeds than the fixtures) and of
+    multiples of the generator: restatement == reference, both directions."""
+    pts, _ = ref.curve_points(curve, group, 1000 + 17 * curve + group, 24)
+    pts = np.concatenate([pts, ref.bases_seq(curve, group, 8, first=5)])
+    enc = ref.disk_write_compressed(curve, group, pts)
+    assert (port.disk_write_compressed(curve, group, pts) == enc).all()
+    back, bad = port.disk_read_compressed(curve, group, enc, pts.shape[0])
+    assert bad == 0 and (back == ref.disk_read_compressed(curve, group, enc, pts.shape[0])).all()
+    assert (back == pts).all()

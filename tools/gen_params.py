@@ -168,6 +168,20 @@ def emit_device_header():
         w(f"    static constexpr uint32_t INV = 0x{f['inv32']:08x}u;   // -p^-1 mod 2^32")
         for cname, v in (("P", p), ("R", f["R"]), ("R2", f["R2"])):
             w(f"    static constexpr uint32_t {cname}[{n}] = {c_arr(limbs(v, n, 32), '0x%08xu')};")
+        # square roots (Fp_model::sqrt, fp.tcc:729-776: Tonelli-Shanks with s, t, nqr_to_t of the
+        # field's init file): p - 1 = 2^s t; s == 1: a^((p+1)/4); else exponent (t-1)/2 and g^t
+        sq_s = ((p - 1) & -(p - 1)).bit_length() - 1
+        t = (p - 1) >> sq_s
+        if sq_s == 1:
+            exp, nqr_t = (p + 1) // 4, 0
+        else:
+            g = next(g for g in range(2, 100) if pow(g, (p - 1) // 2, p) == p - 1)
+            exp, nqr_t = (t - 1) // 2, pow(g, t, p) * f["R"] % p
+        w(f"    static constexpr int SQRT_S = {sq_s};   // 2-adicity of p - 1")
+        w(f"    static constexpr uint32_t SQRT_EXP[{n}] = {c_arr(limbs(exp, n, 32), '0x%08xu')};   "
+          "// (p+1)/4 if SQRT_S == 1, else (t-1)/2")
+        w(f"    static constexpr uint32_t NQR_TO_T[{n}] = {c_arr(limbs(nqr_t, n, 32), '0x%08xu')};   "
+          "// (non-residue)^t, Montgomery form (SQRT_S > 1)")
         w("};")
         w("")
 
