@@ -5,6 +5,7 @@
 #include <hip/hip_runtime_api.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace amdmsm {
 
@@ -29,7 +30,8 @@ inline sort_geom sort_geometry(size_t n, int c, int W) {
     g.hb = (c - 1 < 10) ? c - 1 : 10;
     g.fb = c - 1 - g.hb;
     g.chunk_cap = 1024;   // about twice the expected bin size, 1K .. 16K entries
-    while (g.chunk_cap < 16384u && g.chunk_cap < 2 * (n >> g.hb)) g.chunk_cap <<= 1;
+    static const uint32_t chunk_max = getenv("AMDMSM_SORT_CHUNK_MAX") ? (uint32_t)atoi(getenv("AMDMSM_SORT_CHUNK_MAX")) : 16384u;
+    while (g.chunk_cap < chunk_max && g.chunk_cap < 2 * (n >> g.hb)) g.chunk_cap <<= 1;
     g.big_thresh = 16 * g.chunk_cap;
     g.big_cap = (uint32_t)((size_t)W * n / g.big_thresh + 1);
     g.big_words = 4 + (size_t)g.big_cap * 4 + ((size_t)g.big_cap << g.fb);

@@ -369,7 +369,10 @@ __global__ void __launch_bounds__(SCAN_TPB) k_scan(uint32_t* __restrict__ counts
 //                   then chunk-wise LDS counting sort -> lists[w] (runs per fine bucket)
 // bucket index = |digit| - 1 = (coarse << FB) | fine, HB = min(10, c-1), FB = c-1-HB.
 constexpr int SORT_TPB = 1024;
-constexpr int SORT_TILE = 16384;    // entries per k_sort_coarse workgroup
+#ifndef AMDMSM_SORT_TILE
+#define AMDMSM_SORT_TILE 16384
+#endif
+constexpr int SORT_TILE = AMDMSM_SORT_TILE;    // entries per k_sort_coarse workgroup
 constexpr int SORT_CHUNK = 16384;   // entries per k_sort_fine chunk
 constexpr int SORT_MAX_HB = 10;
 constexpr int SORT_MAX_FB = 11;     // c <= 22
@@ -467,9 +470,9 @@ __global__ void __launch_bounds__(SORT_TPB) k_sort_coarse(const int32_t* __restr
                                                           int hb, uint32_t* __restrict__ cursor,
                                                           uint32_t* __restrict__ tmp_payload,
                                                           uint32_t* __restrict__ tmp_key) {
-    __shared__ uint32_t hist[1 << SORT_MAX_HB], lstart[1 << SORT_MAX_HB], lcur[1 << SORT_MAX_HB],
-        gbase[1 << SORT_MAX_HB], tmp[SORT_TPB / 64 + 1];
+    __shared__ uint32_t hist[1 << SORT_MAX_HB], lstart[1 << SORT_MAX_HB], lcur[1 << SORT_MAX_HB], tmp[SORT_TPB / 64 + 1];
     __shared__ uint32_t st_payload[SORT_TILE], st_key[SORT_TILE];
+    uint32_t* gbase = hist;   // hist[j] is dead once slot j's global base has been reserved
     const uint32_t nbin = 1u << hb;
     const int fb = c - 1 - hb;
     const uint32_t w = blockIdx.y;

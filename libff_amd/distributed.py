@@ -29,6 +29,13 @@ def all_gather_partials(partial_words, group=None):
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
+    if partial_words.is_cuda and dist.get_backend(group) == "gloo":
+        # rehearsal of the multi-rank path with gloo (several ranks sharing one GPU, where RCCL
+        # refuses duplicate devices): stage through the host.  .cpu() waits for the producing stream.
+        host = partial_words.cpu()
+        out = [torch.empty_like(host) for _ in range(world)]
+        dist.all_gather(out, host, group=group)
+        return torch.stack(out, dim=0).to(partial_words.device, non_blocking=False)
     out = [torch.empty_like(partial_words) for _ in range(world)]
     dist.all_gather(out, partial_words, group=group)
     return torch.stack(out, dim=0)

@@ -277,3 +277,65 @@ print("sharded-nccl-ok")
 ''' % (REPO, os.path.join(REPO, "tests"))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "sharded-nccl-ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+def _sharded_rank(rank, world, port_no, n, steps, q):
+    """one rank of test_sharded_msm_two_ranks_one_gpu (spawned: fresh process, own engine context)"""
+    import torch
+    import torch.distributed as dist
+
+    from libff_amd.distributed import ShardedMsm, numpy_words, shard_range
+    from oracle import port
+
+    port.build()
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port_no}", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    curve, group = 0, 1
+    eng = libff_amd.Engine(0)
+    sz = libff_amd.sizes(curve, group)
+    lo, hi = shard_range(n, world, rank)
+    bases = torch.empty((hi - lo, sz["affine_bytes"] // 8), dtype=torch.int64, device=dev)
+    eng.gen_bases_seq_device(curve, group, lo, hi - lo, bases.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    msm = ShardedMsm(eng, curve, group, depth=1)
+    outs = []
+    for step in range(steps):
+        sc_all = port.scalars_sha512(curve, 5000 * step, n)          # every rank draws the same vector ...
+        sc = torch.from_numpy(sc_all[lo:hi].view(np.int64).copy()).to(dev)   # ... and uploads its own range
+        res, _ = msm.run(bases, sc, hi - lo, libff_amd.OUT_AFFINE)
+        msm.synchronize()
+        outs.append(numpy_words(res).copy())
+    q.put((rank, outs))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_msm_two_ranks_one_gpu(port):
+    """The multi-rank path of bench.py --gpus N (ShardedMsm: range shard, all-gather of the partial
+    points, local sum) with TWO ranks, both on the one GPU of the test box (gloo carries the
+    exchange: RCCL refuses two ranks on one device), scalars changing every step: every rank's
+    result at every step == the oracle's MSM over the whole input (odd n: the last range is longer)."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    n, steps, world = 30001, 3, 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port_no = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_rank, args=(r, world, port_no, n, steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    bases = port.bases_seq(0, 1, n, first=0)
+    for step in range(steps):
+        want = port.multi_exp(0, 1, bases, port.scalars_sha512(0, 5000 * step, n), port.BDLO12_SIGNED, 1, chunks=8, omp=True)
+        for r in range(world):
+            assert (got[r][step] == want).all(), (r, step)
