@@ -245,7 +245,7 @@ class Timer:
 
     def max_over_ranks(self, seconds):
         if self.world > 1:
-            tt = torch.tensor([seconds], dtype=torch.float64, device=self.dev)
+            tt = torch.tensor([seconds], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else self.dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             return float(tt.item())
         return seconds
@@ -574,11 +574,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
+    # AMDMSM_BENCH_REHEARSAL=1: every rank uses GPU 0 and gloo carries the collectives -- the multi-rank
+    # code path on a one-GPU box (RCCL refuses several ranks on one device).  Never a measurement.
+    rehearsal = os.environ.get("AMDMSM_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     curve, group = CURVES[args.curve], args.group
     eng = libff_amd.Engine(local_rank)
     tm = Timer(world, dev)
@@ -587,6 +595,8 @@ def main():
     else:
         out = multi_gpu(args, tm, eng, dev, rank, world, curve, group)
     if rank == 0:
+        if rehearsal:
+            out["data"] = "synthetic; REHEARSAL (all ranks share GPU 0, gloo): not a measurement"
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(curve, group, args.cpu_log2n)

@@ -97,6 +97,48 @@ def test_per_rank_shard_sizes_closed_form_and_sharding(engine, port, name, curve
         e2.close()
 
 
+def test_north_star_size_2p26_closed_form(engine, port):
+    """The north-star size on one GPU: alt_bn128 G1, 2^26 points, bit-exact against a closed form.
+    Scalars s_i = pool[i mod 4096] (4096 SHA512_rng values), bases (i+1)G generated on the device, so
+    sum_i s_i (i+1) G = (sum_j pool_j * sum_{i = j mod 4096} (i+1)) G needs 4096 terms on the CPU
+    while the device sorts and accumulates all 13 x 2^26 (point, window) entries.  Then the same
+    input as two uneven ranges on two contexts (amdmsm_msm_device_multi).  Device-resident: the
+    6 GiB of inputs stay in HBM."""
+    curve, group, log2n, m = 0, 1, 26, 4096
+    n = 1 << log2n
+    pool = port.scalars_sha512(curve, 4242, m)
+    plain = port.fr_as_bigint(curve, pool)
+    r = to_int(golden()["alt_bn128_g1/fr_modulus"])
+    reps = n // m
+    k = 0
+    for j in range(m):
+        # i = j + t*m, t < reps: sum (i + 1) = reps*(j + 1) + m * reps*(reps-1)/2
+        k += to_int(plain[j]) * (reps * (j + 1) + m * (reps * (reps - 1) // 2))
+    k %= r
+    fl = pool.shape[1]
+    k_mont = port.fr_from_bigint(curve, np.array([[(k >> (64 * j)) & 0xFFFFFFFFFFFFFFFF for j in range(fl)]], dtype=np.uint64))[0]
+    one, _ = port.group_consts(curve, group)
+    want = port.group_op(curve, group, 4, port.scalar_mul(curve, group, one, k_mont))
+    sc = np.ascontiguousarray(np.tile(pool, (reps, 1)))
+    res = _Resident(engine, curve, group, n, 0, sc)
+    del sc
+    e2 = libff_amd.Engine(0)
+    try:
+        engine.msm_device(curve, group, res.d_bases.value, res.d_sc.value, n, res.d_out.value, out_form=libff_amd.OUT_AFFINE)
+        assert (res.result() == want).all()
+        s = res.s
+        one_r = n // 2 - 3 * m - 1
+        engine.h2d(res.d_out, np.zeros(s["g_bytes"] // 8, dtype=np.uint64))
+        libff_amd.msm_device_multi([engine, e2], curve, group,
+                                   [res.d_bases.value, res.d_bases.value + one_r * s["affine_bytes"]],
+                                   [res.d_sc.value, res.d_sc.value + one_r * s["fr_bytes"]], [one_r, n - one_r],
+                                   res.d_out.value, out_form=libff_amd.OUT_AFFINE)
+        assert (res.result() == want).all()
+    finally:
+        res.free()
+        e2.close()
+
+
 def test_config4_two_msms_issued_together(engine, port):
     """configs[4] per-rank shard: bw6_761 G1 2^21 and bls12_377 G2 2^21 enqueued back to back on two
     contexts (two streams) with no synchronisation in between, as a BW6/BLS12 prover issues
@@ -339,3 +381,27 @@ def test_sharded_msm_two_ranks_one_gpu(port):
         want = port.multi_exp(0, 1, bases, port.scalars_sha512(0, 5000 * step, n), port.BDLO12_SIGNED, 1, chunks=8, omp=True)
         for r in range(world):
             assert (got[r][step] == want).all(), (r, step)
+
+
+def test_bench_multi_rank_path_rehearsal():
+    """bench.py --gpus 2 end to end on the one-GPU box: the script starts its two ranks itself, both
+    use GPU 0 and gloo carries the collectives (AMDMSM_BENCH_REHEARSAL=1; RCCL refuses two ranks on
+    one device).  Checks the contract of the printed line: strong scaling on a fixed total, the
+    configs[4] leg with both MSMs in flight, the weak-scaling leg, rank 0's solo reference."""
+    import json
+    import subprocess
+
+    env = dict(os.environ, AMDMSM_BENCH_REHEARSAL="1")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--log2n", "21", "--config4-log2n", "15"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [x for x in r.stdout.splitlines() if x.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["steps"] == 2 and d["warmup"] == 1
+    assert d["config"]["total_points"] == 1 << 21 and d["config"]["points_per_gpu"] == 1 << 20
+    assert d["value"] > 0 and abs(d["value"] - (1 << 21) / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    legs = d["config"]["legs"]
+    assert set(legs) == {"same_total_on_one_gpu", "weak_2p20_per_gpu", "config4_bw6_761_g1_plus_bls12_377_g2"}
+    assert all(v["value"] > 0 for v in legs.values())
+    assert d["roofline"]["frac"] > 0 and "cpu_baseline" not in d
