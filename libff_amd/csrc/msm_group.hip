@@ -24,6 +24,7 @@
 // becomes the W dimension of every grid.
 #include "curve_params.h"
 #include "ec.cuh"
+#include "fp2h.cuh"
 #include "group_vtable.h"
 #include "wide.cuh"
 
@@ -67,6 +68,17 @@ template <bool I> struct coord_sel<2, I> { using type = Fp2<FQ, GP::NR_SMALL == 
 using E = typename coord_sel<GP::DEG, false>::type;                     // cold kernels
 using EH = typename coord_sel<GP::DEG, (AMDMSM_HOT_INLINE != 0)>::type;  // k_accumulate
 using EI = typename coord_sel<GP::DEG, true>::type;                      // probes only
+// AMDMSM_ACC_SPLIT (G2 groups): k_accumulate keeps every Fq2 element split over a pair of lanes
+// (fp2h.cuh) -- two physical lanes per accumulation lane, half the registers each
+#ifndef AMDMSM_ACC_SPLIT
+#define AMDMSM_ACC_SPLIT 0
+#endif
+template <int DEG> struct split_sel { using type = EH; static constexpr int LANES = 1; };
+#if AMDMSM_ACC_SPLIT
+template <> struct split_sel<2> { using type = Fp2H<FQ, (GP::NR_SMALL == 0 ? -1 : GP::NR_SMALL)>; static constexpr int LANES = 2; };
+#endif
+using EA = typename split_sel<GP::DEG>::type;            // element type of the accumulation loop
+constexpr int ACC_LANES = split_sel<GP::DEG>::LANES;     // physical lanes per accumulation lane
 
 constexpr int EW = FQ::N * GP::DEG;   // words per coordinate
 constexpr int AFFW = 2 * EW;          // words per compact affine point
@@ -754,7 +766,7 @@ __global__ void __launch_bounds__(TPB, AMDMSM_ACC_WAVES) k_accumulate(const uint
                                                     uint32_t* __restrict__ buckets, uint32_t* __restrict__ part_first,
                                                     uint32_t* __restrict__ part_last, uint32_t* __restrict__ cont_bucket,
                                                     int W, uint32_t B, uint32_t S, uint32_t T) {
-    const size_t g = gtid();
+    const size_t g = gtid() / ACC_LANES;   // split form: lanes 2g, 2g+1 work on the same entries
     const size_t w = g / T;
     const uint32_t t = (uint32_t)(g % T);
     if (w >= (size_t)W) return;
@@ -771,7 +783,7 @@ __global__ void __launch_bounds__(TPB, AMDMSM_ACC_WAVES) k_accumulate(const uint
     bool from_prev = (b ? e[b - 1] : 0u) < lo;   // first piece continues a bucket begun earlier
     const uint32_t* lst = lists + w * list_stride;
     uint32_t* bk = buckets + w * (size_t)B * ZZW;
-    Xyzz<EH> acc;
+    Xyzz<EA> acc;
     xyzz_set_inf(acc);
     for (uint32_t k = lo; k < hi; ++k) {
         if (k == bend) {
@@ -786,7 +798,7 @@ __global__ void __launch_bounds__(TPB, AMDMSM_ACC_WAVES) k_accumulate(const uint
             } while (bend == k);   // skip empty buckets (k < total = e[B-1] bounds the walk)
         }
         const uint32_t ent = lst[k];
-        Aff<EH> p;
+        Aff<EA> p;
         load_aff(p, bases + (size_t)(ent & 0x7fffffffu) * AFFW);
         el_cneg(p.y, p.y, (ent >> 31) != 0);   // -(x, y) = (x, -y); (0,0) stays infinity
 #if AMDMSM_ACC_LAZY
@@ -1742,15 +1754,15 @@ void l_sort(hipStream_t st, const uint32_t* scalars, size_t n, int mont, int c, 
 void l_accumulate(hipStream_t st, const uint32_t* ends, const uint32_t* lists, size_t list_stride, const uint32_t* bases,
                   uint32_t* buckets, uint32_t* part_first, uint32_t* part_last, uint32_t* cont_bucket, int W, uint32_t B,
                   uint32_t S, uint32_t T) {
-    hipLaunchKernelGGL(k_accumulate, dim3(blocks_for((size_t)W * T)), dim3(TPB), 0, st, ends, lists, list_stride, bases,
-                       buckets, part_first, part_last, cont_bucket, W, B, S, T);
+    hipLaunchKernelGGL(k_accumulate, dim3(blocks_for((size_t)W * T * ACC_LANES)), dim3(TPB), 0, st, ends, lists, list_stride,
+                       bases, buckets, part_first, part_last, cont_bucket, W, B, S, T);
 }
 size_t l_accumulate_resident_lanes() {
     static const size_t lanes = [] {
         int dev = 0, cus = 256, blocks = 0;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_accumulate, TPB, 0) != hipSuccess || blocks <= 0) blocks = 4;
-        return (size_t)cus * (size_t)blocks * TPB;
+        return (size_t)cus * (size_t)blocks * TPB / ACC_LANES;
     }();
     return lanes;
 }
