@@ -1099,17 +1099,18 @@ int amdmsm_multi_exp_multi(amdmsm_ctx *const *ctxs, int ndev, int curve, int gro
     for (int k = 1; k < ndev; ++k) threads.emplace_back(work, k);
     work(0);
     for (auto &t : threads) t.join();
+    int failed = -1;
     for (int k = 0; k < ndev; ++k) {
-        if (rcs[(size_t)k]) rc = rcs[(size_t)k];
+        if (rcs[(size_t)k] && failed < 0) failed = k;
     }
     dev_guard g0(c0->device);
-    if (rc) {
+    if (failed >= 0) {
         for (int k = 0; k < ndev; ++k) {
             dev_guard g(ctxs[k]->device);
             (void)hipDeviceSynchronize();
         }
-        if (rc && c0->err.empty()) c0->err = "a device range failed";
-        return rc;
+        // amdmsm_last_error is asked of the first context: carry the failing range's message over
+        return fail(c0, rcs[(size_t)failed], "range " + std::to_string(failed) + ": " + ctxs[failed]->err);
     }
     if (!c0->chunk_partials) HIP_TRY(c0, hipMalloc(&c0->chunk_partials, 64 * 3 * 24 * 2 * 4));
     hipStream_t st = c0->stream;
