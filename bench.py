@@ -266,21 +266,20 @@ def timed_msm(tm, eng, msm, bases, scalars, n, steps, warmup, window_bits=0, wan
         msm.run(bases, scalars, n, libff_amd.OUT_LIBFF, window_bits=window_bits)
     msm.synchronize()
     tm.fence()
-    phases, pending = [], []
+    # Steps are enqueued back to back (depth 1: on ONE stream, so the MSMs still run strictly one
+    # after the other); each timed call gets a ticket and the HIP-event phase times of the timed
+    # region are read after it, so no host synchronisation sits between two steps.
+    phases, tickets = [], []
     t0 = time.perf_counter()
     for _ in range(steps):
-        _, slot = msm.run(bases, scalars, n, libff_amd.OUT_LIBFF, window_bits=window_bits)
+        msm.run(bases, scalars, n, libff_amd.OUT_LIBFF, window_bits=window_bits)
         if want_phases:
-            pending.append(slot)
-            # a slot's events are re-recorded when the slot is reused: read a step's HIP-event timings
-            # before the step `depth` later is enqueued (depth 1: right away, one MSM at a time)
-            while len(pending) >= msm.depth:
-                phases.append(eng.get_timings(pending.pop(0)))
-    while pending:
-        phases.append(eng.get_timings(pending.pop(0)))
+            tickets.append(eng.last_timing_ticket())
     msm.synchronize()
     tm.fence()
     elapsed = tm.max_over_ranks(time.perf_counter() - t0)
+    for tk in tickets[-60:]:   # the engine keeps the last 64 tickets
+        phases.append(eng.get_timings(ticket=tk))
     return elapsed, phases
 
 

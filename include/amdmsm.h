@@ -263,6 +263,12 @@ int amdmsm_last_slot(amdmsm_ctx *ctx);
 int amdmsm_set_timing(amdmsm_ctx *ctx, int enable);
 /* milliseconds of the most recent amdmsm_msm_device call; waits for that call */
 int amdmsm_get_timings(amdmsm_ctx *ctx, float ms[AMDMSM_MAX_PHASES]);
+/* every timed call also gets a ticket (0, 1, 2, ...); the phase times of the last 64 tickets stay
+ * readable, so a caller can enqueue MSM after MSM on one stream without synchronising in between
+ * and collect all the timings afterwards.  amdmsm_last_timing_ticket: ticket of the most recent
+ * timed call (-1: none). */
+long long amdmsm_last_timing_ticket(amdmsm_ctx *ctx);
+int amdmsm_get_timings_by_ticket(amdmsm_ctx *ctx, long long ticket, float ms[AMDMSM_MAX_PHASES]);
 /* same for the call that last used workspace slot `slot` */
 int amdmsm_get_slot_timings(amdmsm_ctx *ctx, int slot, float ms[AMDMSM_MAX_PHASES]);
 

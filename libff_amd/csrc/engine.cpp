@@ -38,7 +38,7 @@ struct ws_slot {
     bool used = false;
     hipStream_t side[MAX_GROUPS - 1] = {};
     hipEvent_t acc_done[MAX_GROUPS - 1] = {}, tail_done[MAX_GROUPS - 1] = {};
-    hipEvent_t ev[AMDMSM_MAX_PHASES + 1] = {};
+    long long last_ticket = -1;   // timing ticket of the call that last used the slot
     bool ev_valid = false;
 };
 
@@ -70,6 +70,10 @@ struct amdmsm_ctx {
     int last_slot = 0;
     bool timing = false;
     hipEvent_t ev[AMDMSM_MAX_PHASES + 1] = {};   // probes
+    // phase events of the last TIMING_RING timed MSMs, indexed by ticket % TIMING_RING: a caller
+    // can enqueue MSM after MSM without synchronising and read every call's phase times afterwards
+    hipEvent_t ring[64][6] = {};
+    uint64_t ticket = 0;      // tickets handed out so far (the last call's ticket is ticket - 1)
     void *chunk_partials = nullptr;               // a few points, for calls split into several MSMs
     // host-buffer entry points: staging in HBM reused across calls, a second stream that brings
     // the bases in while the scalars are already being sorted, and the resident base vectors
@@ -269,8 +273,10 @@ int ensure_ws(amdmsm_ctx *ctx, ws_slot &sl, size_t bytes) {
     return AMDMSM_OK;
 }
 
+constexpr uint64_t TIMING_RING = 64;
 void record(amdmsm_ctx *ctx, ws_slot &sl, int idx, hipStream_t st) {
-    if (ctx->timing) (void)hipEventRecord(sl.ev[idx], st);
+    (void)sl;
+    if (ctx->timing) (void)hipEventRecord(ctx->ring[ctx->ticket % TIMING_RING][idx], st);
 }
 
 // The whole single-GPU MSM on device-resident inputs.
@@ -385,6 +391,7 @@ int msm_device_impl(amdmsm_ctx *ctx, const group_vtable *vt, const uint32_t *d_b
         if (!last) HIP_TRY(ctx, hipEventRecord(sl.tail_done[g], ts));
     }
     record(ctx, sl, 5, st);
+    if (ctx->timing) sl.last_ticket = (long long)ctx->ticket++;
     sl.ev_valid = ctx->timing;
     HIP_TRY(ctx, hipEventRecord(sl.done, st));
     sl.used = true;
@@ -444,9 +451,16 @@ int amdmsm_ctx_create(int device, amdmsm_ctx **out) {
         delete ctx;
         return AMDMSM_ERR_HIP;
     }
+    for (auto &set : ctx->ring) {
+        for (auto &e : set) {
+            if (hipEventCreate(&e) != hipSuccess) {
+                delete ctx;
+                return AMDMSM_ERR_HIP;
+            }
+        }
+    }
     for (auto &sl : ctx->slots) {
         bool ok = hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) == hipSuccess;
-        for (auto &e : sl.ev) ok = ok && hipEventCreate(&e) == hipSuccess;
         for (auto &e : sl.tail_done) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
         for (auto &e : sl.acc_done) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
         for (auto &q : sl.side) ok = ok && hipStreamCreateWithFlags(&q, hipStreamNonBlocking) == hipSuccess;
@@ -467,9 +481,6 @@ void amdmsm_ctx_destroy(amdmsm_ctx *ctx) {
         for (auto &sl : ctx->slots) {
             if (sl.ws) (void)hipFree(sl.ws);
             if (sl.done) (void)hipEventDestroy(sl.done);
-            for (auto &e : sl.ev) {
-                if (e) (void)hipEventDestroy(e);
-            }
             for (auto &e : sl.acc_done) {
                 if (e) (void)hipEventDestroy(e);
             }
@@ -482,6 +493,11 @@ void amdmsm_ctx_destroy(amdmsm_ctx *ctx) {
         }
         for (auto &e : ctx->ev) {
             if (e) (void)hipEventDestroy(e);
+        }
+        for (auto &set : ctx->ring) {
+            for (auto &e : set) {
+                if (e) (void)hipEventDestroy(e);
+            }
         }
         if (ctx->chunk_partials) (void)hipFree(ctx->chunk_partials);
         for (grow_buf *b : {&ctx->hb_src, &ctx->hb_aff, &ctx->hb_sc, &ctx->hb_out, &ctx->hb_stats}) {
@@ -551,15 +567,30 @@ int amdmsm_set_pipeline_depth(amdmsm_ctx *ctx, int depth) {
 
 int amdmsm_last_slot(amdmsm_ctx *ctx) { return ctx ? ctx->last_slot : AMDMSM_ERR_BAD_ARG; }
 
+int amdmsm_get_timings_by_ticket(amdmsm_ctx *ctx, long long ticket, float ms[AMDMSM_MAX_PHASES]);
+
 int amdmsm_get_slot_timings(amdmsm_ctx *ctx, int slot, float ms[AMDMSM_MAX_PHASES]) {
     if (!ctx || !ms || slot < 0 || slot >= MAX_SLOTS) return AMDMSM_ERR_BAD_ARG;
-    for (int i = 0; i < AMDMSM_MAX_PHASES; ++i) ms[i] = 0.f;
     ws_slot &sl = ctx->slots[slot];
     if (!sl.ev_valid) return fail(ctx, AMDMSM_ERR_BAD_ARG, "no timed amdmsm_msm_device call recorded in this slot");
+    return amdmsm_get_timings_by_ticket(ctx, sl.last_ticket, ms);
+}
+
+long long amdmsm_last_timing_ticket(amdmsm_ctx *ctx) {
+    if (!ctx || !ctx->timing || ctx->ticket == 0) return -1;
+    return (long long)(ctx->ticket - 1);
+}
+
+int amdmsm_get_timings_by_ticket(amdmsm_ctx *ctx, long long ticket, float ms[AMDMSM_MAX_PHASES]) {
+    if (!ctx || !ms || ticket < 0) return AMDMSM_ERR_BAD_ARG;
+    for (int i = 0; i < AMDMSM_MAX_PHASES; ++i) ms[i] = 0.f;
+    if ((uint64_t)ticket >= ctx->ticket || ctx->ticket - (uint64_t)ticket > TIMING_RING)
+        return fail(ctx, AMDMSM_ERR_BAD_ARG, "timing ticket is not (or no longer) held");
+    hipEvent_t *ev = ctx->ring[(uint64_t)ticket % TIMING_RING];
     dev_guard g(ctx->device);
-    HIP_TRY(ctx, hipEventSynchronize(sl.ev[5]));
-    for (int i = 0; i < 5; ++i) HIP_TRY(ctx, hipEventElapsedTime(&ms[i], sl.ev[i], sl.ev[i + 1]));
-    HIP_TRY(ctx, hipEventElapsedTime(&ms[AMDMSM_PH_TOTAL], sl.ev[0], sl.ev[5]));
+    HIP_TRY(ctx, hipEventSynchronize(ev[5]));
+    for (int i = 0; i < 5; ++i) HIP_TRY(ctx, hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]));
+    HIP_TRY(ctx, hipEventElapsedTime(&ms[AMDMSM_PH_TOTAL], ev[0], ev[5]));
     return AMDMSM_OK;
 }
 

@@ -50,7 +50,8 @@ EXPORTED_SYMBOLS = [
     "amdmsm_multi_exp_stream_with_precompute_file", "amdmsm_precompute_bases_device",
     "amdmsm_msm_precomputed_device", "amdmsm_import_bases_device", "amdmsm_export_affine_device",
     "amdmsm_msm_device", "amdmsm_sum_points_device", "amdmsm_gen_bases_seq_device",
-    "amdmsm_set_timing", "amdmsm_get_timings", "amdmsm_set_pipeline_depth", "amdmsm_last_slot",
+    "amdmsm_set_timing", "amdmsm_get_timings", "amdmsm_last_timing_ticket", "amdmsm_get_timings_by_ticket",
+    "amdmsm_set_pipeline_depth", "amdmsm_last_slot",
     "amdmsm_get_slot_timings", "amdmsm_field_op_device", "amdmsm_group_op_device",
     "amdmsm_digits_device", "amdmsm_mul_bench_device", "amdmsm_madd_bench_device", "amdmsm_malloc", "amdmsm_free",
     "amdmsm_memcpy_h2d", "amdmsm_memcpy_d2h", "amdmsm_synchronize",
@@ -84,6 +85,8 @@ def load_library():
         L.amdmsm_pippenger_optimal_c.restype = ctypes.c_size_t
         L.amdmsm_bdlo12_signed_optimal_c.restype = ctypes.c_size_t
         L.amdmsm_precompute_num_digits.restype = ctypes.c_size_t
+        L.amdmsm_last_timing_ticket.restype = ctypes.c_longlong
+        L.amdmsm_last_timing_ticket.argtypes = [ctypes.c_void_p]
         L.amdmsm_ctx_destroy.restype = None
         L.amdmsm_ctx_destroy.argtypes = [ctypes.c_void_p]
         _lib = L
@@ -494,9 +497,16 @@ class Engine:
     def last_slot(self):
         return int(self.lib.amdmsm_last_slot(self.h))
 
-    def get_timings(self, slot=None):
+    def last_timing_ticket(self):
+        """ticket of the most recent timed MSM (see amdmsm_get_timings_by_ticket); -1 if none"""
+        return int(self.lib.amdmsm_last_timing_ticket(self.h))
+
+    def get_timings(self, slot=None, ticket=None):
         ms = (ctypes.c_float * MAX_PHASES)()
-        if slot is None:
+        if ticket is not None:
+            self._check(self.lib.amdmsm_get_timings_by_ticket(self.h, ctypes.c_longlong(ticket), ms),
+                        "amdmsm_get_timings_by_ticket")
+        elif slot is None:
             self._check(self.lib.amdmsm_get_timings(self.h, ms), "amdmsm_get_timings")
         else:
             self._check(self.lib.amdmsm_get_slot_timings(self.h, int(slot), ms), "amdmsm_get_slot_timings")
