@@ -32,6 +32,11 @@ GROUP_FLAGS["alt_bn128_g1"] = GROUP_FLAGS["alt_bn128_g1"] + ["-DAMDMSM_ACC_WAVES
 # (249 VGPRs, two waves).
 for _g in ("bls12_377_g2", "bls12_381_g2", "bw6_761_g1", "bw6_761_g2"):
     GROUP_FLAGS[_g] = GROUP_FLAGS[_g] + ["-DAMDMSM_ACC_WAVES=2"]
+# 8- and 12-limb G1: Montgomery products inlined in the cold kernels too (fix-up, bucket reduction,
+# butterfly; no call / operand moves around the ~1 us product of a lone wave): reduction phase
+# 0.72 -> 0.66 ms (alt_bn128 2^20), 2.74 -> 2.10 ms (bls12_377 2^22).  No gain for Fq2 / 24 limbs.
+for _g in ("alt_bn128_g1", "bls12_377_g1", "bls12_381_g1"):
+    GROUP_FLAGS[_g] = GROUP_FLAGS[_g] + ["-DAMDMSM_COLD_INLINE=1"]
 # Fq2 groups: every element split over a pair of lanes in k_accumulate (fp2h.cuh): same
 # multiply-accumulate count, half the registers per lane -- bls12_377 G2 256 VGPRs + 16 B of scratch
 # at two waves instead of + 440 B: 22.4 -> 18.1 ms at 2^21 (1.86 G madd/s, 0.90 of the MAC bound);

@@ -65,7 +65,10 @@ using FR = typename GP::fr;
 template <int DEG, bool I> struct coord_sel;
 template <bool I> struct coord_sel<1, I> { using type = Fp<FQ, I>; };
 template <bool I> struct coord_sel<2, I> { using type = Fp2<FQ, GP::NR_SMALL == 0 ? -1 : GP::NR_SMALL, I>; };
-using E = typename coord_sel<GP::DEG, false>::type;                     // cold kernels
+#ifndef AMDMSM_COLD_INLINE
+#define AMDMSM_COLD_INLINE 0
+#endif
+using E = typename coord_sel<GP::DEG, (AMDMSM_COLD_INLINE != 0)>::type;   // cold kernels
 using EH = typename coord_sel<GP::DEG, (AMDMSM_HOT_INLINE != 0)>::type;  // k_accumulate
 using EI = typename coord_sel<GP::DEG, true>::type;                      // probes only
 // AMDMSM_ACC_SPLIT (G2 groups): k_accumulate keeps every Fq2 element split over a pair of lanes
@@ -1326,9 +1329,10 @@ AMDMSM_DEV void load_be_raw(Fp<FQ, I>& r, const uint32_t* __restrict__ src) {
 #pragma unroll
     for (int j = 0; j < FQ::N; ++j) r.v[j] = bswap32(src[FQ::N - 1 - j]);
 }
-AMDMSM_DEV void load_coord_disk(Fp<FQ, false>& r, const uint32_t* src) { load_be_raw(r, src); }
-template <int NR>
-AMDMSM_DEV void load_coord_disk(Fp2<FQ, NR, false>& r, const uint32_t* src) {
+template <bool I>
+AMDMSM_DEV void load_coord_disk(Fp<FQ, I>& r, const uint32_t* src) { load_be_raw(r, src); }
+template <int NR, bool I>
+AMDMSM_DEV void load_coord_disk(Fp2<FQ, NR, I>& r, const uint32_t* src) {
     load_be_raw(r.c0, src);
     load_be_raw(r.c1, src + FQ::N);
 }
@@ -1352,9 +1356,10 @@ __global__ void __launch_bounds__(TPB) k_disk_decode(const uint32_t* __restrict_
 // representation, bit 1 = the element is zero.  Y = sqrt(X^3 + b) (curve_point_y_at_x,
 // curve_utils.tcc:34-47), negated when its low bit disagrees with the flag.  status |= 2 where
 // X^3 + b has no square root (the reference's sqrt does not terminate on such input).
-AMDMSM_DEV const Fp<FQ, false>& coord_c0(const Fp<FQ, false>& a) { return a; }
-template <int NR>
-AMDMSM_DEV const Fp<FQ, false>& coord_c0(const Fp2<FQ, NR, false>& a) { return a.c0; }
+template <bool I>
+AMDMSM_DEV const Fp<FQ, I>& coord_c0(const Fp<FQ, I>& a) { return a; }
+template <int NR, bool I>
+AMDMSM_DEV const Fp<FQ, I>& coord_c0(const Fp2<FQ, NR, I>& a) { return a.c0; }
 
 __global__ void __launch_bounds__(64) k_disk_decode_compressed(const uint32_t* __restrict__ src, size_t n,
                                                                  uint32_t* __restrict__ dst, uint32_t* __restrict__ status) {
@@ -1495,16 +1500,18 @@ AMDMSM_DEV void store_be_plain(uint32_t* __restrict__ dst, const Fp<FQ, I>& a) {
 #pragma unroll
     for (int j = 0; j < FQ::N; ++j) dst[FQ::N - 1 - j] = bswap32(a.v[j]);
 }
-AMDMSM_DEV bool load_coord_be(Fp<FQ, false>& r, const uint32_t* src) { return load_be_plain(r, src); }
-AMDMSM_DEV void store_coord_be(uint32_t* dst, const Fp<FQ, false>& a) { store_be_plain(dst, a); }
-template <int NR>
-AMDMSM_DEV bool load_coord_be(Fp2<FQ, NR, false>& r, const uint32_t* src) {
+template <bool I>
+AMDMSM_DEV bool load_coord_be(Fp<FQ, I>& r, const uint32_t* src) { return load_be_plain(r, src); }
+template <bool I>
+AMDMSM_DEV void store_coord_be(uint32_t* dst, const Fp<FQ, I>& a) { store_be_plain(dst, a); }
+template <int NR, bool I>
+AMDMSM_DEV bool load_coord_be(Fp2<FQ, NR, I>& r, const uint32_t* src) {
     const bool ok1 = load_be_plain(r.c1, src);   // field_serializer: coeffs[degree-1] first (:25-36)
     const bool ok0 = load_be_plain(r.c0, src + FQ::N);
     return ok0 && ok1;
 }
-template <int NR>
-AMDMSM_DEV void store_coord_be(uint32_t* dst, const Fp2<FQ, NR, false>& a) {
+template <int NR, bool I>
+AMDMSM_DEV void store_coord_be(uint32_t* dst, const Fp2<FQ, NR, I>& a) {
     store_be_plain(dst, a.c1);
     store_be_plain(dst + FQ::N, a.c0);
 }

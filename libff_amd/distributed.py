@@ -99,17 +99,20 @@ class ShardedMsm:
         partial, result = self.partial[i], self.result[i]
         # inputs were produced on the caller's current stream
         stream.wait_stream(torch.cuda.current_stream(stream.device))
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.pg) > 1
         with torch.cuda.stream(stream):
+            if not multi:
+                # one rank: the MSM writes the requested form itself, nothing to exchange or sum
+                self.engine.msm_device(self.curve, self.group_id, bases_affine.data_ptr(), scalars.data_ptr(), n,
+                                       result.data_ptr(), out_form=out_form, window_bits=window_bits,
+                                       stream=stream.cuda_stream)
+                return result, self.engine.last_slot()
             self.engine.msm_device(self.curve, self.group_id, bases_affine.data_ptr(), scalars.data_ptr(), n,
                                    partial.data_ptr(), out_form=OUT_JACOBIAN, window_bits=window_bits,
                                    stream=stream.cuda_stream)
             slot = self.engine.last_slot()
-            if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.pg) > 1:
-                stacked = all_gather_partials(partial, group=self.pg).contiguous()
-                k = stacked.shape[0]
-            else:
-                stacked, k = partial, 1
-            self.engine.sum_points_device(self.curve, self.group_id, stacked.data_ptr(), k, out_form,
+            stacked = all_gather_partials(partial, group=self.pg).contiguous()
+            self.engine.sum_points_device(self.curve, self.group_id, stacked.data_ptr(), stacked.shape[0], out_form,
                                           result.data_ptr(), stream=stream.cuda_stream)
         return result, slot
 
