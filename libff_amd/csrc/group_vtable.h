@@ -27,7 +27,17 @@ struct sort_geom {
 };
 inline sort_geom sort_geometry(size_t n, int c, int W) {
     sort_geom g;
-    g.hb = (c - 1 < 10) ? c - 1 : 10;
+    // coarse / fine split of the c-1 bucket-index bits: about half each, at most 10 coarse and 11
+    // fine bits (LDS tables of the two passes).  Measured (profiles/r02_sort_hb_sweep.txt): with
+    // c = 16, 8 coarse bits beat 10 at every size from 2^16 to 2^23 (2^20: 0.27 vs 0.29 ms,
+    // 2^16: 0.07 vs 0.09); around 2^20 points 7 is better still (0.24 ms).  AMDMSM_SORT_HB overrides.
+    static const int hb_env = getenv("AMDMSM_SORT_HB") ? atoi(getenv("AMDMSM_SORT_HB")) : 0;
+    g.hb = c / 2 < 10 ? c / 2 : 10;
+    if (c == 16 && n >= ((size_t)3 << 18) && n < ((size_t)3 << 19)) g.hb = 7;
+    if (hb_env > 0) g.hb = hb_env;
+    if (g.hb > c - 1) g.hb = c - 1;
+    if (g.hb < 1) g.hb = 1;
+    if (c - 1 - g.hb > 11) g.hb = c - 1 - 11;   // the fine pass handles at most 11 bits
     g.fb = c - 1 - g.hb;
     g.chunk_cap = 1024;   // about twice the expected bin size, 1K .. 16K entries
     static const uint32_t chunk_max = getenv("AMDMSM_SORT_CHUNK_MAX") ? (uint32_t)atoi(getenv("AMDMSM_SORT_CHUNK_MAX")) : 16384u;
