@@ -143,25 +143,41 @@ struct plan_t {
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-// Window size.  Measured on MI355X (alt_bn128 G1; the other fields scale both terms alike):
-// sort + accumulation cost ~0.137 ns per (point, window) entry and the bucket reduction
-// ~0.8 ns per bucket, with a latency floor.  A top window that keeps only 2..8 significant bits concentrates all of
+// Window size.  Cost model fitted to measurements on MI355X (alt_bn128 G1, tools/sweep_c.py; the other
+// fields scale every term alike, the wide ones pay more per bucket because their reduction
+// kernels spill).  From 2^23 points up: sort + accumulation ~0.10 ns per (point, window) entry;
+// fix-up + bucket reduction ~0.35 ms + 0.5 ns per bucket (0.98 ms for 16 x 2^16 buckets, 3.1 - 5.0
+// for 13 x 2^19).  Below that the reduction is a latency floor (~0.65 ms from 2^16 points up) and
+// c = 16 -- 2^15 buckets, exactly one reduction lane per SIMD lane -- is the measured optimum for
+// every group from 2^16 to 2^22 points (c = 15 is slower even in the reduction: 0.74 vs 0.64 ms);
+// the round-1 constants reproduce that and are kept there.  A top window that keeps only 2..8 significant bits concentrates all of
 // its n entries in a handful of buckets, which the second sort level (one workgroup per coarse
 // bin) processes almost serially -- such c are penalised rather than forbidden.
 int choose_c(const group_vtable *vt, size_t n) {
     if (n == 0) return 2;
     double best = 1e300;
     int best_c = 2;
+    const bool large = n >= ((size_t)1 << 23);
     for (int c = 2; c <= 22; ++c) {
         const int W = (vt->fr_bits + 2 + c - 1) / c;
         const double B = (double)((size_t)1 << (c - 1));
-        // the reduction's dependent chain takes ~0.65 ms however few buckets there are (measured
-        // from 2^16 points up; below that the small-c regime with tiny bucket sets is faster)
-        // (wider coordinates: the reduction kernels spill, a bucket costs relatively more)
         const double wide = (vt->fq_words > 8 || vt->el_words > vt->fq_words) ? 1.5 : 1.0;
-        double reduce_cost = (double)W * B * 0.8 * wide;
-        if (n >= 65536) reduce_cost = std::max(reduce_cost, 0.65e6);
-        double cost = (double)W * (double)n * 0.137 + reduce_cost;
+        // windows that can hold a nonzero digit: with W * c well above the scalar length the top
+        // window sees neither a scalar bit nor the carry (c = 17: 15 of 16 windows for a 254-bit
+        // Fr) -- measured to pay from 2^23 points up (2^23: c = 17 14.4 ms vs c = 16 15.0 ms;
+        // at 2^21 / 2^22 the accumulation time does not drop and c = 16 stays ahead)
+        int W_work = W;
+        if (n >= ((size_t)1 << 23)) {
+            while (W_work > 1 && (W_work - 1) * c >= vt->fr_bits + 1) --W_work;
+        }
+        double cost;
+        if (large) {
+            cost = (double)W_work * (double)n * 0.10 + 0.35e6 + (double)W * B * 0.5 * wide;
+        } else {
+            double reduce_cost = (double)W * B * 0.8 * wide;
+            if (n >= 65536) reduce_cost = std::max(reduce_cost, 0.65e6);
+            cost = (double)W * (double)n * 0.137 + reduce_cost;
+        }
         const int top_bits = vt->fr_bits + 1 - (W - 1) * c;   // bit positions left for the top window
         if (top_bits >= 2 && top_bits <= 8) cost += (double)n * 3.0 / (double)(1 << (top_bits - 1));
         if (cost < best) {
@@ -183,12 +199,14 @@ int make_plan(const group_vtable *vt, size_t n, int c_req, int L_req, plan_t &p,
     p.W = table_digits ? 1 : (vt->fr_bits + 2 + p.c - 1) / p.c;
     p.D = table_digits;
     p.B = (uint32_t)1 << (p.c - 1);
-    // buckets per reduction lane: longer segments amortise the per-segment scalar multiple and
-    // wave fold (~40 vs ~70 field products per bucket at L = 32 vs 8) once there are enough
-    // lanes to fill the chip; short ones keep the latency down for small bucket counts
-    uint32_t L = 8u;
-    while (L < 32u && (size_t)p.W * p.B / (2 * L) >= (size_t)262144) L <<= 1;
-    while (L > 2u && (size_t)p.W * p.B / L < (size_t)16384) L >>= 1;
+    // buckets per reduction lane.  k_reduce_segments is bound by the dependent chain of one wave
+    // (2 L additions + the segment-offset multiple + the 64:1 fold), so the best L is the one that
+    // gives every SIMD about one wave: W * B / L ~ 65536 lanes (1024 waves), L in 2 .. 64.
+    // Measured (alt_bn128 G1, reduction phase incl. fix-up): 2^20, c = 16: L = 4 / 8 / 16 ->
+    // 0.86 / 0.66 / 0.84 ms; 2^23, c = 17: 8 / 16 / 32 -> 1.15 / 1.01 / 1.32; 2^26, c = 20:
+    // 8 / 16 / 32 / 64 / 128 -> 6.80 / 5.43 / 5.09 / 5.09 / 5.62.
+    uint32_t L = 2u;
+    while (L < 64u && (size_t)p.W * p.B / (2 * L) >= (size_t)65536) L <<= 1;
     // 24-limb prime field (bw6_761): a product is ~9x an 8-limb one and the kernel runs one wave
     // per SIMD, so fewer, longer lanes win (measured 8.1 vs 10.7 ms at 2^21)
     if (vt->fq_words >= 24 && L == 8u && (size_t)p.W * p.B / 16 >= (size_t)32768) L = 16u;
