@@ -205,8 +205,11 @@ int make_plan(const group_vtable *vt, size_t n, int c_req, int L_req, plan_t &p,
     // Measured (alt_bn128 G1, reduction phase incl. fix-up): 2^20, c = 16: L = 4 / 8 / 16 ->
     // 0.86 / 0.66 / 0.84 ms; 2^23, c = 17: 8 / 16 / 32 -> 1.15 / 1.01 / 1.32; 2^26, c = 20:
     // 8 / 16 / 32 / 64 / 128 -> 6.80 / 5.43 / 5.09 / 5.09 / 5.62.
+    // (groups whose reduction lanes are two physical lanes wide -- fp2h.cuh, reduce_fold == 32 --
+    // need twice the L for the same wave count: bls12_377 G2 2^21 3.87 -> 2.96 ms with L = 16)
+    const size_t red_lanes = (size_t)(64 / vt->reduce_fold);
     uint32_t L = 2u;
-    while (L < 64u && (size_t)p.W * p.B / (2 * L) >= (size_t)65536) L <<= 1;
+    while (L < 64u && (size_t)p.W * p.B * red_lanes / (2 * L) >= (size_t)65536) L <<= 1;
     // 24-limb prime field (bw6_761): a product is ~9x an 8-limb one and the kernel runs one wave
     // per SIMD, so fewer, longer lanes win (measured 8.1 vs 10.7 ms at 2^21)
     if (vt->fq_words >= 24 && L == 8u && (size_t)p.W * p.B / 16 >= (size_t)32768) L = 16u;
@@ -249,7 +252,7 @@ int make_plan(const group_vtable *vt, size_t n, int c_req, int L_req, plan_t &p,
     p.off_lvl0 = off;
     off = align_up(off + (size_t)p.W * M * xyz_bytes, 256);
     p.off_lvl1 = off;
-    off = align_up(off + (size_t)p.W * ((M + p.L - 1) / p.L) * xyz_bytes, 256);
+    off = align_up(off + (size_t)p.W * (M / 2 + 1) * xyz_bytes, 256);   // first fold leaves at most M / 32 points
     p.off_pfirst = off;
     off = align_up(off + (size_t)p.W * p.T * zz_bytes, 256);
     p.off_plast = off;
@@ -366,7 +369,7 @@ int msm_device_impl(amdmsm_ctx *ctx, const group_vtable *vt, const uint32_t *d_b
         if (wait_for) HIP_TRY(ctx, hipStreamWaitEvent(st, wait_for, 0));
     }
     const size_t zzw = (size_t)vt->el_words * 4, xyzw = (size_t)vt->el_words * 3;   // words per XYZZ / Jacobian point
-    const size_t M0 = p.B / p.L, cap1 = (M0 + p.L - 1) / p.L;
+    const size_t M0 = p.B / p.L, cap1 = M0 / 2 + 1;
     uint32_t *pfirst = (uint32_t *)(ws + p.off_pfirst), *plast = (uint32_t *)(ws + p.off_plast);
     uint32_t *cont = (uint32_t *)(ws + p.off_cont), *partial = (uint32_t *)(ws + p.off_partial);
     // groups of windows, highest first: [w0, w0 + wg)
@@ -394,11 +397,12 @@ int msm_device_impl(amdmsm_ctx *ctx, const group_vtable *vt, const uint32_t *d_b
                              (uint32_t *)(ws + p.off_queue + g * p.queue_stride), wg, p.B, p.S, p.T);
         uint32_t *src = lvl0 + (size_t)w0 * M0 * xyzw, *dst = lvl1 + (size_t)w0 * cap1 * xyzw;
         vt->reduce_segments(ts, buckets + (size_t)w0 * p.B * zzw, wg, p.B, p.L, src);
+        const uint32_t fold = (uint32_t)vt->reduce_fold;
         uint32_t M = (uint32_t)M0;
-        M /= std::min<uint32_t>(M, 64u);   // folded per wave inside reduce_segments
+        M /= std::min<uint32_t>(M, fold);   // folded per wave inside reduce_segments
         while (M > 1) {
             vt->sum_butterfly(ts, src, wg, M, dst);
-            M /= std::min<uint32_t>(M, 64u);
+            M /= std::min<uint32_t>(M, fold);
             std::swap(src, dst);
         }
         // Horner over this group's windows, continuing from the groups above

@@ -52,6 +52,9 @@ template <class P, int NR> AMDMSM_DEV void el_one(Fp2H<P, NR>& r) {
 }
 template <class P, int NR> AMDMSM_DEV bool el_is_zero(const Fp2H<P, NR>& a) { return pair_and(fp_is_zero(a.h)); }
 template <class P, int NR> AMDMSM_DEV bool el_is_zero_lz(const Fp2H<P, NR>& a) { return pair_and(fp_is_zero_lz(a.h)); }
+template <class P, int NR> AMDMSM_DEV bool el_eq(const Fp2H<P, NR>& a, const Fp2H<P, NR>& b) { return pair_and(fp_eq(a.h, b.h)); }
+// the element held by the pair whose lane index differs by `mask` (mask even: pairs stay pairs)
+template <class P, int NR> AMDMSM_DEV void el_shfl_xor(Fp2H<P, NR>& r, const Fp2H<P, NR>& a, int mask) { el_shfl_xor(r.h, a.h, mask); }
 template <class P, int NR> AMDMSM_DEV void el_add(Fp2H<P, NR>& r, const Fp2H<P, NR>& a, const Fp2H<P, NR>& b) { fp_add(r.h, a.h, b.h); }
 template <class P, int NR> AMDMSM_DEV void el_sub(Fp2H<P, NR>& r, const Fp2H<P, NR>& a, const Fp2H<P, NR>& b) { fp_sub(r.h, a.h, b.h); }
 template <class P, int NR> AMDMSM_DEV void el_dbl(Fp2H<P, NR>& r, const Fp2H<P, NR>& a) { fp_dbl(r.h, a.h); }

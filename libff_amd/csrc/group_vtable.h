@@ -66,6 +66,7 @@ struct group_vtable {
     int fq_words;      // 32-bit limbs of the base prime field
     int fr_bits;       // bit length of the scalar-field modulus
     int projective;    // libff stores this group in homogeneous projective coordinates
+    int reduce_fold;   // segments / points one wave of reduce_segments / sum_butterfly folds (64 or 32)
     const uint32_t* fr_one_mont;   // Fr::one() in Montgomery form (R mod r), fr_words words
 
     // libff (X, Y, Z) records -> compact affine (x, y); (0, 0) = infinity.
@@ -107,10 +108,10 @@ struct group_vtable {
     void (*accumulate_fixup)(hipStream_t, const uint32_t* ends, uint32_t* buckets, uint32_t* part_first,
                              const uint32_t* part_last, const uint32_t* cont_bucket, uint32_t* queue, int W,
                              uint32_t B, uint32_t S, uint32_t T);
-    // M = B/L segments per window, G = min(M, 64):
+    // M = B/L segments per window, G = min(M, reduce_fold):
     // out[w][g] = sum over segments s in [g*G, (g+1)*G) of sum_j (s*L + j + 1) * bucket[w][s*L + j]
     void (*reduce_segments)(hipStream_t, const uint32_t* buckets, int W, uint32_t B, uint32_t L, uint32_t* out);
-    // out[w][g] = sum_{i in [g*G, (g+1)*G)} in[w][i], G = min(M, 64)
+    // out[w][g] = sum_{i in [g*G, (g+1)*G)} in[w][i], G = min(M, reduce_fold)
     void (*sum_butterfly)(hipStream_t, const uint32_t* in, int W, uint32_t M, uint32_t* out);
     // Horner over window sums (high to low, c doublings between), write one point; init (engine
     // Jacobian, may be null) = value carried in from the windows above window_sums[W-1]

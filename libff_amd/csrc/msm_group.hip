@@ -82,6 +82,11 @@ template <> struct split_sel<2> { using type = Fp2H<FQ, (GP::NR_SMALL == 0 ? -1 
 #endif
 using EA = typename split_sel<GP::DEG>::type;            // element type of the accumulation loop
 constexpr int ACC_LANES = split_sel<GP::DEG>::LANES;     // physical lanes per accumulation lane
+// the bucket reduction (k_reduce_segments, k_sum_butterfly) uses the same split form: a wave then
+// folds 32 segments instead of 64
+using ER = typename std::conditional<(ACC_LANES == 2), EA, E>::type;
+constexpr int RED_LANES = ACC_LANES;
+constexpr uint32_t RED_FOLD = 64u / RED_LANES;
 
 constexpr int EW = FQ::N * GP::DEG;   // words per coordinate
 constexpr int AFFW = 2 * EW;          // words per compact affine point
@@ -982,24 +987,34 @@ AMDMSM_DEV void wave_group_sum(Jac<E>& p, uint32_t G) {
     }
 }
 
+// Wave-level plain sum over RED_FOLD neighbouring reduction lanes (a reduction lane is RED_LANES
+// physical lanes wide): XOR butterfly, infinity outside the data.
+AMDMSM_DEV void wave_group_sum_r(Jac<ER>& p, uint32_t G) {
+    Jac<ER> other;
+    for (uint32_t off = 1; off < G; off <<= 1) {
+        jac_shfl_xor(other, p, (int)(off * RED_LANES));
+        jac_add(p, p, other);
+    }
+}
+
 // sum_b (b + 1) * B_b for one window, first level: each lane takes L consecutive buckets
 // with the running-sum recurrence of multiexp_accumulate_buckets (multiexp.tcc:109-122),
 // adds (s*L) * (plain sum) for the weight offset of its segment, and the wave then folds
-// G = min(M, 64) neighbouring segments.  out[w][s / G].
+// G = min(M, RED_FOLD) neighbouring segments.  out[w][s / G].
 __global__ void __launch_bounds__(64) k_reduce_segments(const uint32_t* __restrict__ buckets, int W, uint32_t B,
                                                         uint32_t L, uint32_t* __restrict__ out) {
-    const size_t t = gtid();
+    const size_t t = gtid() / RED_LANES;
     const uint32_t M = B / L;
-    const uint32_t G = M < 64u ? M : 64u;
+    const uint32_t G = M < RED_FOLD ? M : RED_FOLD;
     const size_t w = t / M;
     const uint32_t s = (uint32_t)(t % M);
     const bool valid = w < (size_t)W;
-    Jac<E> acc, sum, bk;
+    Jac<ER> acc, sum, bk;
     jac_set_inf(acc);
     jac_set_inf(sum);
     if (valid) {
         const uint32_t* seg = buckets + (w * B + (size_t)s * L) * ZZW;
-        Xyzz<E> xa, xs, xb;
+        Xyzz<ER> xa, xs, xb;
         xyzz_set_inf(xa);
         xyzz_set_inf(xs);
         for (uint32_t j = L; j-- > 0;) {
@@ -1013,21 +1028,21 @@ __global__ void __launch_bounds__(64) k_reduce_segments(const uint32_t* __restri
         jac_mul_u64(bk, acc, (unsigned long long)s * L);
         jac_add(sum, sum, bk);
     }
-    wave_group_sum(sum, G);
+    wave_group_sum_r(sum, G);
     if (valid && (s % G) == 0) store_jac(out + (w * (M / G) + s / G) * XYZW, sum);
 }
 
-// plain sums: out[w][i / G] = sum of in[w][i .. i + G), G = min(M, 64)
+// plain sums: out[w][i / G] = sum of in[w][i .. i + G), G = min(M, RED_FOLD)
 __global__ void __launch_bounds__(64) k_sum_butterfly(const uint32_t* __restrict__ in, int W, uint32_t M,
                                                       uint32_t* __restrict__ out) {
-    const size_t t = gtid();
-    const uint32_t G = M < 64u ? M : 64u;
+    const size_t t = gtid() / RED_LANES;
+    const uint32_t G = M < RED_FOLD ? M : RED_FOLD;
     const size_t w = t / M;
     const uint32_t i = (uint32_t)(t % M);
     const bool valid = w < (size_t)W;
-    Jac<E> p;
+    Jac<ER> p;
     if (valid) load_jac(p, in + t * XYZW); else jac_set_inf(p);
-    wave_group_sum(p, G);
+    wave_group_sum_r(p, G);
     if (valid && (i % G) == 0) store_jac(out + (w * (M / G) + i / G) * XYZW, p);
 }
 
@@ -1789,10 +1804,11 @@ void l_accumulate_fixup(hipStream_t st, const uint32_t* ends, uint32_t* buckets,
                        part_first, part_last, cont_bucket, buckets, queue, 0, 64u, lanes, B, S, T);
 }
 void l_reduce_segments(hipStream_t st, const uint32_t* buckets, int W, uint32_t B, uint32_t L, uint32_t* out) {
-    hipLaunchKernelGGL(k_reduce_segments, dim3(blocks_for((size_t)W * (B / L), 64)), dim3(64), 0, st, buckets, W, B, L, out);
+    hipLaunchKernelGGL(k_reduce_segments, dim3(blocks_for((size_t)W * (B / L) * RED_LANES, 64)), dim3(64), 0, st, buckets, W, B,
+                       L, out);
 }
 void l_sum_butterfly(hipStream_t st, const uint32_t* in, int W, uint32_t M, uint32_t* out) {
-    hipLaunchKernelGGL(k_sum_butterfly, dim3(blocks_for((size_t)W * M, 64)), dim3(64), 0, st, in, W, M, out);
+    hipLaunchKernelGGL(k_sum_butterfly, dim3(blocks_for((size_t)W * M * RED_LANES, 64)), dim3(64), 0, st, in, W, M, out);
 }
 void l_horner(hipStream_t st, const uint32_t* window_sums, int W, int c, int form, const uint32_t* init, uint32_t* out) {
     hipLaunchKernelGGL(k_horner, dim3(1), dim3(64), 0, st, window_sums, W, c, form, init, out);
@@ -1880,7 +1896,7 @@ void l_madd_bench(hipStream_t st, const uint32_t* pts, uint32_t* out, size_t nth
 }
 
 const group_vtable g_vt = {
-    GP::CURVE, GP::GROUP, FRW, EW, FQ::N, FR::BITS, GP::LIBFF_PROJECTIVE ? 1 : 0, FR::R,
+    GP::CURVE, GP::GROUP, FRW, EW, FQ::N, FR::BITS, GP::LIBFF_PROJECTIVE ? 1 : 0, (int)RED_FOLD, FR::R,
     l_import_bases, l_precompute_table, l_count, l_scatter, l_scalar_stats, l_sort, l_accumulate, l_accumulate_resident_lanes, l_accumulate_fixup, l_reduce_segments, l_sum_butterfly, l_horner, l_sum_points,
     l_gen_bases_seq, l_export_affine, l_ffi_decode_points, l_ffi_decode_scalars, l_ffi_encode_point, l_disk_decode, l_disk_decode_compressed, l_fixed_base_exp, l_field_op, l_group_op, l_digits, l_mul_bench, l_madd_bench,
 };
