@@ -219,8 +219,8 @@ def cpu_baseline(curve, group, log2n):
     for chunks in sorted({max(1, cores // 4), max(1, cores // 2), cores}):
         multi[chunks] = min(run(bases, scalars, chunks) for _ in range(2))
     best = min(multi, key=multi.get)
-    # chunks = 1 is one core for ~n / 45k seconds: a quarter of the workload keeps the default run short
-    n1 = n if n <= (1 << 18) else n // 4
+    # chunks = 1: one core, the whole workload (about 7 s for 2^20 points on this class of host)
+    n1 = n if n <= (1 << 20) else (1 << 20)
     t1 = run(bases[:n1], scalars[:n1], 1)
     return {"value": n / multi[best], "unit": "scalar-muls/s", "cores": min(best, cores), "kind": kind,
             "cpu": cpu_model(), "host_cores": cores,
