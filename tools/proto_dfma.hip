@@ -29,13 +29,16 @@ constexpr int ITERS = 2048;
 constexpr int UNROLL = 8;
 
 __device__ __forceinline__ void set_f64_round_toward_zero() {
-    // MODE register (hwreg 1), bits [3:2] = rounding mode of f64 / f16 operations; 3 = toward zero
-    __builtin_amdgcn_s_setreg(1 | (2 << 6) | (1 << 11), 3);
+    // MODE register, bits [3:2] = rounding mode of f64 / f16 operations; 3 = toward zero.  Written
+    // as inline asm: after __builtin_amdgcn_s_setreg the compiler's own mode-register pass puts the
+    // default mode back in front of the next floating-point instruction it knows about.
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 3");
 }
 
 __device__ __forceinline__ void split52(double x, double y, uint64_t& hi52, uint64_t& lo52) {
     const double c1 = 0x1p104, c2 = 0x1p104 + 0x1p52;
     double hi, sub, lo;
+    set_f64_round_toward_zero();
     asm volatile("v_fma_f64 %0, %1, %2, %3" : "=v"(hi) : "v"(x), "v"(y), "v"(c1));
     asm volatile("v_add_f64 %0, %1, -%2" : "=v"(sub) : "v"(c2), "v"(hi));
     asm volatile("v_fma_f64 %0, %1, %2, %3" : "=v"(lo) : "v"(x), "v"(y), "v"(sub));
