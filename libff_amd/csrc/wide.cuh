@@ -210,6 +210,33 @@ AMDMSM_DEV void jac_dbl_wide(const WideEnv<P>& e, uint32_t& X, uint32_t& Y, uint
     Z = wide_dbl<P>(e, YZ);
 }
 
+// The same doubling for fields of 16..31 limbs (bw6_761: two 32-lane rows per wave): the seven
+// products in four rounds of two -- (X^2, Y^2), (Y Z, B^2), ((X+B)^2, E^2), E (D - X3) -- instead of
+// one after the other.  Same value as jac_dbl / jac_dbl_seq.
+template <class P>
+AMDMSM_DEV void jac_dbl_wide2(const WideEnv<P>& e, uint32_t& X, uint32_t& Y, uint32_t& Z) {
+    static_assert(WideEnv<P>::ROW == 32, "two rows");
+    const bool r1 = (threadIdx.x & 32u) != 0;
+    uint32_t r = wide_mul<P>(e, r1 ? Y : X, r1 ? Y : X);           // row 0: XX   row 1: B = Y^2
+    const uint32_t XX = row_copy<P>(e, r, 0), B = row_copy<P>(e, r, 1);
+    r = wide_mul<P>(e, r1 ? B : Y, r1 ? B : Z);                    // row 0: Y Z  row 1: C = B^2
+    const uint32_t YZ = row_copy<P>(e, r, 0);
+    uint32_t C = row_copy<P>(e, r, 1);
+    const uint32_t E3 = wide_add<P>(e, wide_dbl<P>(e, XX), XX);    // E = 3 XX
+    const uint32_t XB = wide_add<P>(e, X, B);
+    r = wide_mul<P>(e, r1 ? E3 : XB, r1 ? E3 : XB);                // row 0: (X+B)^2   row 1: F = E^2
+    uint32_t D = row_copy<P>(e, r, 0);
+    const uint32_t F = row_copy<P>(e, r, 1);
+    D = wide_sub<P>(e, D, XX);
+    D = wide_sub<P>(e, D, C);
+    D = wide_dbl<P>(e, D);                                         // D = 2((X+B)^2 - XX - C)
+    X = wide_sub<P>(e, F, wide_dbl<P>(e, D));                      // X3 = F - 2D
+    const uint32_t t = wide_mul<P>(e, E3, wide_sub<P>(e, D, X));   // both rows: E (D - X3)
+    C = wide_dbl<P>(e, wide_dbl<P>(e, wide_dbl<P>(e, C)));         // 8C
+    Y = wide_sub<P>(e, t, C);
+    Z = wide_dbl<P>(e, YZ);
+}
+
 // wave-uniform test of a quad that every row holds a copy of
 AMDMSM_DEV bool wide_is_zero(uint32_t w) { return __ballot(w != 0u) == 0ull; }
 

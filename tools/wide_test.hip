@@ -31,7 +31,7 @@ __global__ void __launch_bounds__(64) k_test(const uint32_t* in, uint32_t* out_w
         // doubling of (a, b, c) of row 0, replicated
         uint32_t X = row_copy<P>(e, a, 0), Y = row_copy<P>(e, b, 0), Z = row_copy<P>(e, c, 0);
         if constexpr (ROW == 16) jac_dbl_wide<P>(e, X, Y, Z);
-        else jac_dbl_seq<WideFq<P>, P>(e, X, Y, Z);
+        else jac_dbl_wide2<P>(e, X, Y, Z);
         res[4] = X;
         res[5] = Y;
         res[6] = Z;
