@@ -287,7 +287,9 @@ def roofline_of(curve_name, curve, group, n_launch, plan, acc_ms, log2n_for_pmc)
     algo_bytes = ALGO_BYTES[(curve, group)] * n_launch
     achieved = algo_bytes / (acc_ms * 1e-3) / 1e9
     fq_products = FQ_PRODUCTS_PER_MADD[group if not (curve == 2) else 1]
-    lane_instr = float(n_launch) * plan["num_windows"] * fq_products * 4 * FQ_LIMBS[curve] ** 2
+    # list entries: one per (digit column, window); the endomorphism split has two half-length columns per point
+    columns = 2 if plan.get("endomorphism") else 1
+    lane_instr = float(n_launch) * columns * plan["num_windows"] * fq_products * 4 * FQ_LIMBS[curve] ** 2
     mac_rate = lane_instr / (acc_ms * 1e-3)
     return {
         "bound": "hbm",
@@ -411,7 +413,8 @@ def single_gpu(args, tm, eng, dev, curve, group):
         legs[f"points_2p{args.extra_log2n}"] = {
             "workload": f"{args.curve} G{group} MSM, 2^{args.extra_log2n} points on one GPU (the north-star target size)",
             "steps": k2, "value": n2 * k2 / e2, "unit": "scalar-muls/s", "ms_per_step": e2 / k2 * 1e3,
-            "window_bits": p2["c"], "num_windows": p2["num_windows"], "phases_ms": mean_phases(ph2)}
+            "window_bits": p2["c"], "num_windows": p2["num_windows"], "endomorphism_split": p2["endomorphism"],
+            "phases_ms": mean_phases(ph2)}
         roof2 = roofline_of(args.curve, curve, group, n2, p2, acc2, args.extra_log2n)
         del bases2, scalars2
 
@@ -439,6 +442,7 @@ def single_gpu(args, tm, eng, dev, curve, group):
             "total_points": n,
             "window_bits": plan["c"],
             "num_windows": plan["num_windows"],
+            "endomorphism_split": plan["endomorphism"],
             "parallelism": "1 GPU",
             "msms_in_flight": msm.depth,
             "phases_ms": mean_phases(phases),
@@ -502,7 +506,10 @@ def multi_gpu(args, tm, eng, dev, rank, world, curve, group):
             t4 = 1 << args.config4_log2n
             lo4, hi4 = shard_range(t4, world, rank)
             n4 = hi4 - lo4
-            eng2 = libff_amd.Engine(eng.device)   # second context: its own stream and workspace
+            # (both groups have a cofactor: the bases here are multiples of the generator, so the
+            # endomorphism split is permitted explicitly -- amdmsm_opts.endomorphism = 1)
+            eng2 = libff_amd.Engine(eng.device, endomorphism=1)   # second context: its own stream and workspace
+            eng.endomorphism = 1
             jobs = []
             for e, (cv, gp) in ((eng, (2, 1)), (eng2, (1, 2))):
                 b4, s4 = gen_inputs(e, cv, gp, lo4, n4, dev, 777 + rank)
@@ -528,9 +535,10 @@ def multi_gpu(args, tm, eng, dev, rank, world, curve, group):
                 "value": 2 * t4 * k4 / e4, "unit": "scalar-muls/s", "ms_per_step": e4 / k4 * 1e3, "steps": k4,
                 "what": f"BASELINE configs[4]: bw6_761 G1 MSM + bls12_377 G2 MSM, 2^{args.config4_log2n} points in total each "
                         f"({n4} per rank), both issued together on two streams per rank; a step = both MSMs incl. their "
-                        "all-gathers; value counts the scalar-muls of both"}
+                        "all-gathers; value counts the scalar-muls of both; endomorphism split permitted (bases in the order-r subgroup)"}
             del jobs
             eng2.close()
+            eng.endomorphism = 0
 
     out = {
         "metric": "G1 MSM throughput (scalar-muls/sec)" if group == 1 else "G2 MSM throughput (scalar-muls/sec)",
@@ -553,6 +561,7 @@ def multi_gpu(args, tm, eng, dev, rank, world, curve, group):
             "total_points": total,
             "window_bits": plan["c"],
             "num_windows": plan["num_windows"],
+            "endomorphism_split": plan["endomorphism"],
             "parallelism": f"range-sharded x{world} (multiexp.tcc:663-687 with rank = chunk), all-gather of partial points "
                            "+ local sum",
             "msms_in_flight": 1,

@@ -80,6 +80,12 @@ typedef struct amdmsm_opts {
     int out_form;      /* AMDMSM_OUT_* ; host entry points default to AMDMSM_OUT_LIBFF */
     int scalars_plain; /* nonzero: scalars are plain bigints, not Montgomery residues */
     void *stream;      /* hipStream_t to launch on (device entry points); NULL = context stream */
+    int endomorphism;  /* k P as k1 P + k2 phi(P), phi(x, y) = (beta x, y), half-length k1, k2: half the windows
+                          (bucket reduction and final doublings).  Exact where phi = [lambda], i.e. on the order-r
+                          subgroup libff's G1 / G2 are.  0 = permitted only where the whole curve group has order r
+                          (alt_bn128 G1), 1 = permitted: the caller guarantees every base lies in that subgroup,
+                          2 = same guarantee, used at every size, -1 = never.  Where permitted the engine uses it
+                          when it pays (below ~2^22 points; amdmsm_plan_ex tells) */
 } amdmsm_opts;
 
 #define AMDMSM_MAX_PHASES 8
@@ -105,6 +111,11 @@ int amdmsm_sizes(int curve, int group, size_t out[4]);
 /* window size / round count / bucket count / workspace the engine would use */
 int amdmsm_plan(int curve, int group, size_t n, int window_bits, int *c, int *num_windows,
                 uint32_t *num_buckets, size_t *workspace_bytes);
+
+/* the same with amdmsm_opts.endomorphism given; *endomorphism_used = 1 when the plan splits the scalars
+   (num_windows then covers the half-length scalars and the lists hold 2n columns) */
+int amdmsm_plan_ex(int curve, int group, size_t n, int window_bits, int endomorphism, int *c, int *num_windows,
+                   uint32_t *num_buckets, size_t *workspace_bytes, int *endomorphism_used);
 
 /* libff's own window heuristics, kept for API parity (multiexp.hpp:53-57) */
 size_t amdmsm_pippenger_optimal_c(size_t num_elements);
@@ -281,6 +292,14 @@ int amdmsm_digits_device(amdmsm_ctx *ctx, int curve, int group, const void *d_sc
                          int scalars_plain, int c, int num_windows, int32_t *d_out);
 /* throughput probes (2*iters dependent Fq products / iters mixed additions per lane);
  * *ms receives the kernel time from HIP events on the context stream */
+/* endomorphism split (amdmsm_opts.endomorphism): lambda (plain integer, sizeof(Fr) bytes) with
+   phi(P) = [lambda]P on the order-r subgroup, ceil(1000 log2) of the bound on |k1|, |k2|, and whether the
+   whole curve group has order r.  The digits hook returns the signed digits of both halves,
+   d_out[(2 i + half) * num_windows + w], so that sum_w d 2^(c w) over half 0 plus lambda times the same over
+   half 1 is scalar i (mod r). */
+int amdmsm_endomorphism_info(int curve, int group, void *lambda_plain, int *bound_log2_x1000, int *prime_order);
+int amdmsm_endomorphism_digits_device(amdmsm_ctx *ctx, int curve, int group, const void *d_scalars, size_t n,
+                                      int scalars_plain, int c, int num_windows, int32_t *d_out);
 int amdmsm_mul_bench_device(amdmsm_ctx *ctx, int curve, int group, void *d_inout, size_t nthreads,
                             int iters, int inline_variant, float *ms);
 int amdmsm_madd_bench_device(amdmsm_ctx *ctx, int curve, int group, const void *d_points_affine,

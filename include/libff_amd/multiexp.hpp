@@ -135,6 +135,18 @@ inline size_t &min_points_per_device()
     return n;
 }
 
+/// amdmsm_opts.endomorphism of every call made through this header (include/amdmsm.h).  0, the
+/// default: the engine splits scalars along the curve's endomorphism only for alt_bn128 G1, whose
+/// every curve point has order r.  1 asserts what libff's own constructors guarantee -- G1 / G2
+/// values are elements of the order-r subgroup -- and lets the other groups use it too (5-10 %
+/// at 2^20..2^21 points); leave it at 0 if bases may come unchecked from untrusted input
+/// (is_well_formed() tests the curve equation only).  -1 switches it off.
+inline int &endomorphism_mode()
+{
+    static int m = 0;
+    return m;
+}
+
 /// (curve, group) ids of the C ABI for a libff group type; specialised below
 /// for the supported groups when their headers have been included.
 template<typename GroupT> struct group_id;
@@ -154,6 +166,7 @@ GroupT gpu_multi_exp_inner(
     GroupT result = GroupT::zero();
     amdmsm_opts opts = {};
     opts.out_form = AMDMSM_OUT_LIBFF;
+    opts.endomorphism = endomorphism_mode();
     const int rc = amdmsm_multi_exp(
         default_context(),
         group_id<GroupT>::curve,
@@ -199,6 +212,7 @@ GroupT gpu_multi_exp(
     GroupT result = GroupT::zero();
     amdmsm_opts opts = {};
     opts.out_form = AMDMSM_OUT_LIBFF;
+    opts.endomorphism = endomorphism_mode();
     const void *b = n ? static_cast<const void *>(&*vec_start) : nullptr;
     const void *s = n ? static_cast<const void *>(&*scalar_start) : nullptr;
     const int form = BaseForm == libff::multi_exp_base_form_special

@@ -36,6 +36,7 @@ GroupT gpu_multi_exp_stream(
     GroupT result = GroupT::zero();
     amdmsm_opts opts = {};
     opts.out_form = AMDMSM_OUT_LIBFF;
+    opts.endomorphism = endomorphism_mode();
     const int rc = (compressed ? amdmsm_multi_exp_stream_compressed
                                : amdmsm_multi_exp_stream)(
         default_context(),

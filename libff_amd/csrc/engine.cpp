@@ -139,9 +139,23 @@ struct plan_t {
     size_t off_pfirst = 0, off_plast = 0, off_cont = 0, off_queue = 0;
     size_t off_coarse = 0, off_cursor = 0, off_tmp_payload = 0, off_tmp_key = 0, off_big = 0;
     size_t list_stride = 0;
+    bool glv = false;        // endomorphism split: the sorted columns are 2 * n_real half-length scalars
+    size_t off_endo = 0;     // phi(P) = (beta x, y) of every base, compact affine
 };
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Windows needed for signed radix-2^c digits of the half scalars of the endomorphism split,
+// |k| <= 2^lb: the recoded top digit must not carry out, i.e. 2^lb < 2^(cW-1) - 2^(c(W-1))
+// (the "+ 2" of field_get_signed_digit's bits + 2, multiexp.tcc:584-586, with the real bound in
+// place of the bit length: alt_bn128 |k| < 2^125.8 fits 8 windows of 16 bits).
+int glv_windows(const group_vtable *vt, int c) {
+    const double lb = vt->glv_bound_log2_x1000 / 1000.0 + 1e-3;
+    int W = 1;
+    while ((double)(c * W - 1) + std::log2(1.0 - std::ldexp(1.0, 1 - c)) < lb) ++W;
+    return W;
+}
+int num_windows(const group_vtable *vt, int c, bool glv) { return glv ? glv_windows(vt, c) : (vt->fr_bits + 2 + c - 1) / c; }
 
 // Window size.  Cost model fitted to measurements on MI355X (alt_bn128 G1, tools/sweep_c.py; the other
 // fields scale every term alike, the wide ones pay more per bucket because their reduction
@@ -153,50 +167,76 @@ size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 // the round-1 constants reproduce that and are kept there.  A top window that keeps only 2..8 significant bits concentrates all of
 // its n entries in a handful of buckets, which the second sort level (one workgroup per coarse
 // bin) processes almost serially -- such c are penalised rather than forbidden.
-int choose_c(const group_vtable *vt, size_t n) {
+//
+// Modelled time (ns, alt_bn128 G1 scale) of an MSM over n points with window size c, with or without
+// the endomorphism split.  The split doubles the digit columns and halves their length: about the
+// same number of bucket entries, half the buckets to reduce and half the final doublings
+// (~1.95 us each) -- measured on alt_bn128 G1 2^16 / 2^18 / 2^20 / 2^21 points: 1.02 vs 1.34,
+// 1.34 vs 1.71, 2.66 vs 2.98, 4.64 vs 4.72 ms; its entries cost ~3 % more below 2^22 points (x and
+// y of phi(P) come from two arrays) and ~8 % more above, where the base loads miss the caches, so
+// from 2^22 points up the plain path is ahead again (2^23: 15.1 vs 14.5, 2^26: 94.4 vs 92.1 ms;
+// profiles/r02_endomorphism_sweep.txt).
+double plan_cost(const group_vtable *vt, size_t n, int c, bool glv) {
+    const int bits = glv ? (vt->glv_bound_log2_x1000 + 999) / 1000 : vt->fr_bits;
+    const int W = num_windows(vt, c, glv);
+    const double cols = glv ? 2.0 * (double)n : (double)n;   // digit columns
+    const double B = (double)((size_t)1 << (c - 1));
+    // (24 limbs: the reduction kernels run one wave per SIMD; ~10 ns per bucket against 0.8 for 8 limbs,
+    // while an accumulation entry costs 8.3x)
+    const double wide = vt->fq_words >= 24 ? 2.2 : ((vt->fq_words > 8 || vt->el_words > vt->fq_words) ? 1.5 : 1.0);
+    // (the wider fields hide the second base load behind their longer additions: same rate either way)
+    const double entry = !glv ? 1.0 : (n < ((size_t)1 << 22) ? (wide > 1.0 ? 1.0 : 1.03) : (wide > 1.0 ? 1.02 : 1.08));
+    const bool large = n >= ((size_t)1 << 23);
+    // windows that can hold a nonzero digit: with W * c well above the scalar length the top
+    // window sees neither a scalar bit nor the carry (c = 17: 15 of 16 windows for a 254-bit
+    // Fr) -- measured to pay from 2^23 points up (2^23: c = 17 14.4 ms vs c = 16 15.0 ms;
+    // at 2^21 / 2^22 the accumulation time does not drop and c = 16 stays ahead)
+    int W_work = W;
+    if (large) {
+        while (W_work > 1 && (W_work - 1) * c >= bits + 1) --W_work;
+    }
+    double cost;
+    if (large) {
+        cost = (double)W_work * cols * 0.10 * entry + 0.35e6 + (double)W * B * 0.5 * wide;
+    } else {
+        double reduce_cost = (double)W * B * 0.8 * wide;
+        if (n >= 65536) reduce_cost = std::max(reduce_cost, 0.65e6);
+        cost = (double)W * cols * 0.137 * entry + reduce_cost;
+    }
+    cost += (double)W * c * 1.95e3;   // final doublings
+    const int top_bits = bits + 1 - (W - 1) * c;   // bit positions left for the top window
+    if (top_bits >= 2 && top_bits <= 8) cost += cols * 3.0 / (double)(1 << (top_bits - 1));
+    return cost;
+}
+
+// n: points
+int choose_c(const group_vtable *vt, size_t n, bool glv = false, double *cost_out = nullptr) {
     if (n == 0) return 2;
     double best = 1e300;
     int best_c = 2;
-    const bool large = n >= ((size_t)1 << 23);
     for (int c = 2; c <= 22; ++c) {
-        const int W = (vt->fr_bits + 2 + c - 1) / c;
-        const double B = (double)((size_t)1 << (c - 1));
-        const double wide = (vt->fq_words > 8 || vt->el_words > vt->fq_words) ? 1.5 : 1.0;
-        // windows that can hold a nonzero digit: with W * c well above the scalar length the top
-        // window sees neither a scalar bit nor the carry (c = 17: 15 of 16 windows for a 254-bit
-        // Fr) -- measured to pay from 2^23 points up (2^23: c = 17 14.4 ms vs c = 16 15.0 ms;
-        // at 2^21 / 2^22 the accumulation time does not drop and c = 16 stays ahead)
-        int W_work = W;
-        if (n >= ((size_t)1 << 23)) {
-            while (W_work > 1 && (W_work - 1) * c >= vt->fr_bits + 1) --W_work;
-        }
-        double cost;
-        if (large) {
-            cost = (double)W_work * (double)n * 0.10 + 0.35e6 + (double)W * B * 0.5 * wide;
-        } else {
-            double reduce_cost = (double)W * B * 0.8 * wide;
-            if (n >= 65536) reduce_cost = std::max(reduce_cost, 0.65e6);
-            cost = (double)W * (double)n * 0.137 + reduce_cost;
-        }
-        const int top_bits = vt->fr_bits + 1 - (W - 1) * c;   // bit positions left for the top window
-        if (top_bits >= 2 && top_bits <= 8) cost += (double)n * 3.0 / (double)(1 << (top_bits - 1));
+        const double cost = plan_cost(vt, n, c, glv);
         if (cost < best) {
             best = cost;
             best_c = c;
         }
     }
+    if (cost_out) *cost_out = best;
     return best_c;
 }
 
 // table_digits > 0: every scalar contributes table_digits entries (one per digit, pointing at
 // its precomputed multiple) to a single bucket set; n is then the number of ENTRIES.
+// glv: n counts the 2 x points digit columns of the endomorphism split
 int make_plan(const group_vtable *vt, size_t n, int c_req, int L_req, plan_t &p, int S_req = 0, int table_digits = 0,
-              int G_req = 0) {
+              int G_req = 0, bool glv = false) {
     if (c_req < 0 || c_req > 24 || c_req == 1) return AMDMSM_ERR_BAD_ARG;
     if (table_digits && (c_req < 2 || c_req > 22)) return AMDMSM_ERR_BAD_ARG;
-    p.c = c_req ? c_req : choose_c(vt, n);
+    if (glv && (table_digits || c_req > 22)) return AMDMSM_ERR_BAD_ARG;
+    p.glv = glv;
+    p.c = c_req ? c_req : choose_c(vt, glv ? n / 2 : n, glv);
     // field_get_signed_digit needs room for bits + 2 (multiexp.tcc:584-586)
-    p.W = table_digits ? 1 : (vt->fr_bits + 2 + p.c - 1) / p.c;
+    p.W = table_digits ? 1 : num_windows(vt, p.c, glv);
     p.D = table_digits;
     p.B = (uint32_t)1 << (p.c - 1);
     // buckets per reduction lane.  k_reduce_segments is bound by the dependent chain of one wave
@@ -211,8 +251,12 @@ int make_plan(const group_vtable *vt, size_t n, int c_req, int L_req, plan_t &p,
     uint32_t L = 2u;
     while (L < 64u && (size_t)p.W * p.B * red_lanes / (2 * L) >= (size_t)65536) L <<= 1;
     // 24-limb prime field (bw6_761): a product is ~9x an 8-limb one and the kernel runs one wave
-    // per SIMD, so fewer, longer lanes win (measured 8.1 vs 10.7 ms at 2^21)
-    if (vt->fq_words >= 24 && L == 8u && (size_t)p.W * p.B / 16 >= (size_t)32768) L = 16u;
+    // per SIMD, so fewer, longer lanes win (measured 8.1 vs 10.7 ms at 2^21 with L = 16 vs 8)
+    // (and never more lanes than the device holds at once: 12 windows of the endomorphism split at
+    // 2^20 points, L = 4 / 8 / 16 -> 8.1 / 5.6 / 6.8 ms)
+    if (vt->fq_words >= 24) {
+        while (L < 64u && (size_t)p.W * p.B / L > (size_t)65536) L <<= 1;
+    }
     if (L_req > 0) L = (uint32_t)L_req;
     while (L > p.B) L >>= 1;
     if (L == 0 || (L & (L - 1))) return AMDMSM_ERR_BAD_ARG;
@@ -276,6 +320,8 @@ int make_plan(const group_vtable *vt, size_t n, int c_req, int L_req, plan_t &p,
     off = align_up(off + (size_t)p.W * p.list_stride * 4, 256);
     p.off_big = off;
     if (p.c <= 22) off = align_up(off + sort_geometry(n, p.c, p.W).big_words * 4, 256);
+    p.off_endo = off;
+    if (glv) off = align_up(off + (n / 2) * (size_t)vt->el_words * 2 * 4, 256);
     p.total = off;
     return AMDMSM_OK;
 }
@@ -306,6 +352,43 @@ void record(amdmsm_ctx *ctx, ws_slot &sl, int idx, hipStream_t st) {
 // before_accumulate (optional): called once the bucket sort has been enqueued -- the sort reads
 // only the scalars, so a host entry uses it to bring the bases in on another stream meanwhile;
 // it returns an event the accumulation must wait for (or null).
+// The endomorphism split (msm_group.hip glv_split) computes k P as k1 P + k2 phi(P), which equals
+// k P exactly where phi = [lambda]: on the order-r subgroup.  opts->endomorphism: 0 = permitted only
+// for groups whose whole curve has order r (alt_bn128 G1: every base qualifies), 1 = permitted: the
+// caller guarantees subgroup membership of every base (libff's G1 / G2 are that subgroup; the FFI
+// entry points check it while decoding), 2 = the same guarantee, and use it whatever the size,
+// -1 = never.  Where permitted it is used when the cost model favours it (plan_cost).
+// AMDMSM_GLV=off|auto|on|force overrides the option (experiments).
+bool use_endomorphism(const group_vtable *vt, size_t n, const amdmsm_opts *opts, int table_digits) {
+    static const int env = [] {
+        const char *e = getenv("AMDMSM_GLV");
+        if (!e) return 0;
+        if (!strcmp(e, "off") || !strcmp(e, "0")) return -1;
+        if (!strcmp(e, "on") || !strcmp(e, "1")) return 1;
+        if (!strcmp(e, "all") || !strcmp(e, "force") || !strcmp(e, "2")) return 2;
+        if (!strcmp(e, "auto")) return 3;
+        return 0;
+    }();
+    if (table_digits || n == 0 || n >= ((size_t)1 << 30)) return false;
+    const int c_req = opts ? opts->window_bits : 0;
+    if (c_req > 22) return false;
+    int want = opts ? opts->endomorphism : 0;
+    if (env == -1 || env == 1 || env == 2) want = env;
+    if (env == 3) want = 0;
+    if (want < 0 || (want == 0 && !vt->prime_order)) return false;
+    if (want >= 2) return true;
+    // permitted: used where the model says it pays (small and medium inputs)
+    double full = 0, split = 0;
+    if (c_req) {
+        full = plan_cost(vt, n, c_req, false);
+        split = plan_cost(vt, n, c_req, true);
+    } else {
+        choose_c(vt, n, false, &full);
+        choose_c(vt, n, true, &split);
+    }
+    return split < 0.98 * full;
+}
+
 struct msm_hook {
     int (*fn)(void *arg, hipEvent_t *wait_for) = nullptr;
     void *arg = nullptr;
@@ -316,7 +399,9 @@ int msm_device_impl(amdmsm_ctx *ctx, const group_vtable *vt, const uint32_t *d_b
     hipStream_t st = (opts && opts->stream) ? (hipStream_t)opts->stream : ctx->stream;
     const int form = opts ? opts->out_form : AMDMSM_OUT_LIBFF;
     const int mont = (opts && opts->scalars_plain) ? 0 : 1;
-    const size_t entries = table_digits ? n * (size_t)table_digits : n;   // per sorted list
+    static const bool atomic_sort = getenv("AMDMSM_SORT") && !strcmp(getenv("AMDMSM_SORT"), "atomic");
+    const bool glv = use_endomorphism(vt, n, opts, table_digits) && !atomic_sort;
+    const size_t entries = table_digits ? n * (size_t)table_digits : (glv ? 2 * n : n);   // per sorted list
     if (entries >= ((size_t)1 << 31)) return fail(ctx, AMDMSM_ERR_TOO_LARGE, "n (times table digits) must be < 2^31 per call");
     if (n == 0) {
         // empty sum = zero; sum_points over 0 points writes G::zero() in the requested form
@@ -329,7 +414,7 @@ int msm_device_impl(amdmsm_ctx *ctx, const group_vtable *vt, const uint32_t *d_b
     static const int acc_s_env = getenv("AMDMSM_ACC_S") ? atoi(getenv("AMDMSM_ACC_S")) : 0;
     static const int groups_env = getenv("AMDMSM_WINDOW_GROUPS") ? atoi(getenv("AMDMSM_WINDOW_GROUPS")) : 0;
     int rc = make_plan(vt, entries, opts ? opts->window_bits : 0, opts ? opts->segment_len : 0, p, acc_s_env, table_digits,
-                       groups_env);
+                       groups_env, glv);
     if (rc) return fail(ctx, rc, "bad window_bits / segment_len");
     const int slot_idx = (int)(ctx->next++ % (unsigned)ctx->depth);
     ws_slot &sl = ctx->slots[slot_idx];
@@ -345,7 +430,11 @@ int msm_device_impl(amdmsm_ctx *ctx, const group_vtable *vt, const uint32_t *d_b
     uint32_t *lvl1 = (uint32_t *)(ws + p.off_lvl1);
 
     record(ctx, sl, 0, st);
-    static const bool atomic_sort = getenv("AMDMSM_SORT") && !strcmp(getenv("AMDMSM_SORT"), "atomic");
+    // phi(P) of every base (endomorphism split): independent of the sort, so it runs beside it on
+    // the slot's side stream when the bases are already on the device (no upload hook)
+    uint32_t *endo_pts = glv ? (uint32_t *)(ws + p.off_endo) : nullptr;
+    const bool endo_beside = glv && !(hook && hook->fn);
+    if (endo_beside) HIP_TRY(ctx, hipEventRecord(sl.tail_done[0], st));
     if ((atomic_sort || p.c > 22) && !table_digits) {
         HIP_TRY(ctx, hipMemsetAsync(counts, 0, (size_t)p.W * p.B * 4, st));
         vt->count(st, d_scalars, n, mont, p.c, p.W, counts);
@@ -358,7 +447,14 @@ int msm_device_impl(amdmsm_ctx *ctx, const group_vtable *vt, const uint32_t *d_b
         vt->sort(st, d_scalars, n, mont, p.c, table_digits ? table_digits : p.W, (uint32_t *)(ws + p.off_coarse),
                  (uint32_t *)(ws + p.off_cursor), (int32_t *)lists, (uint32_t *)(ws + p.off_tmp_payload),
                  (uint32_t *)(ws + p.off_tmp_key), counts, lists, p.list_stride, (uint32_t *)(ws + p.off_big),
-                 table_digits ? 1 : 0);
+                 table_digits ? 1 : (glv ? 2 : 0), nullptr);
+    }
+    // (measured at 2^20 points: beside the whole sort 0.29 ms for the phase, beside its LDS-bound
+    // second half only 0.35, after it 0.30; the plain path's sort takes 0.24)
+    if (endo_beside) {   // enqueued after the sort kernels, ordered only behind the start of the call
+        HIP_TRY(ctx, hipStreamWaitEvent(sl.side[0], sl.tail_done[0], 0));
+        vt->endo_points(sl.side[0], d_bases, n, endo_pts);
+        HIP_TRY(ctx, hipEventRecord(sl.acc_done[0], sl.side[0]));
     }
     HIP_TRY(ctx, hipMemsetAsync(buckets, 0, (size_t)p.W * p.B * vt->el_words * 16, st));
     for (int g = 0; g < p.G; ++g) HIP_TRY(ctx, hipMemsetAsync(ws + p.off_queue + g * p.queue_stride, 0, 8, st));
@@ -368,6 +464,8 @@ int msm_device_impl(amdmsm_ctx *ctx, const group_vtable *vt, const uint32_t *d_b
         if (rc) return rc;
         if (wait_for) HIP_TRY(ctx, hipStreamWaitEvent(st, wait_for, 0));
     }
+    if (endo_beside) HIP_TRY(ctx, hipStreamWaitEvent(st, sl.acc_done[0], 0));
+    else if (glv) vt->endo_points(st, d_bases, n, endo_pts);
     const size_t zzw = (size_t)vt->el_words * 4, xyzw = (size_t)vt->el_words * 3;   // words per XYZZ / Jacobian point
     const size_t M0 = p.B / p.L, cap1 = M0 / 2 + 1;
     uint32_t *pfirst = (uint32_t *)(ws + p.off_pfirst), *plast = (uint32_t *)(ws + p.off_plast);
@@ -385,7 +483,7 @@ int msm_device_impl(amdmsm_ctx *ctx, const group_vtable *vt, const uint32_t *d_b
         if (g == 0) record(ctx, sl, 2, st);
         vt->accumulate(st, counts + (size_t)w0 * p.B, lists + (size_t)w0 * p.list_stride, p.list_stride, d_bases,
                        buckets + (size_t)w0 * p.B * zzw, pfirst + (size_t)w0 * p.T * zzw, plast + (size_t)w0 * p.T * zzw,
-                       cont + (size_t)w0 * p.T, wg, p.B, p.S, p.T);
+                       cont + (size_t)w0 * p.T, wg, p.B, p.S, p.T, endo_pts, n);
         if (last) {
             record(ctx, sl, 3, st);
         } else {
@@ -546,18 +644,28 @@ int amdmsm_sizes(int curve, int group, size_t out[4]) {
     return AMDMSM_OK;
 }
 
-int amdmsm_plan(int curve, int group, size_t n, int window_bits, int *c, int *num_windows, uint32_t *num_buckets,
-                size_t *workspace_bytes) {
+int amdmsm_plan_ex(int curve, int group, size_t n, int window_bits, int endomorphism, int *c, int *num_windows,
+                   uint32_t *num_buckets, size_t *workspace_bytes, int *endomorphism_used) {
     const group_vtable *vt = find_vt(curve, group);
     if (!vt) return AMDMSM_ERR_UNSUPPORTED;
+    amdmsm_opts o = {};
+    o.window_bits = window_bits;
+    o.endomorphism = endomorphism;
+    const bool glv = use_endomorphism(vt, n, &o, 0);
     plan_t p;
-    const int rc = make_plan(vt, n, window_bits, 0, p);
+    const int rc = make_plan(vt, glv ? 2 * n : n, window_bits, 0, p, 0, 0, 0, glv);
     if (rc) return rc;
     if (c) *c = p.c;
     if (num_windows) *num_windows = p.W;
     if (num_buckets) *num_buckets = p.B;
     if (workspace_bytes) *workspace_bytes = p.total;
+    if (endomorphism_used) *endomorphism_used = glv ? 1 : 0;
     return AMDMSM_OK;
+}
+
+int amdmsm_plan(int curve, int group, size_t n, int window_bits, int *c, int *num_windows, uint32_t *num_buckets,
+                size_t *workspace_bytes) {
+    return amdmsm_plan_ex(curve, group, n, window_bits, 0, c, num_windows, num_buckets, workspace_bytes, nullptr);
 }
 
 size_t amdmsm_pippenger_optimal_c(size_t num_elements) {
@@ -773,6 +881,25 @@ int amdmsm_digits_device(amdmsm_ctx *ctx, int curve, int group, const void *d_sc
     vt->digits(ctx->stream, (const uint32_t *)d_scalars, n, scalars_plain ? 0 : 1, c, num_windows, d_out);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return AMDMSM_OK;
+}
+
+int amdmsm_endomorphism_digits_device(amdmsm_ctx *ctx, int curve, int group, const void *d_scalars, size_t n,
+                                      int scalars_plain, int c, int num_windows, int32_t *d_out) {
+    GET_VT(ctx, curve, group);
+    if (c < 2 || c > 24 || num_windows < 1) return fail(ctx, AMDMSM_ERR_BAD_ARG, "c / num_windows");
+    vt->glv_digits(ctx->stream, (const uint32_t *)d_scalars, n, scalars_plain ? 0 : 1, c, num_windows, d_out);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return AMDMSM_OK;
+}
+
+int amdmsm_endomorphism_info(int curve, int group, void *lambda_plain, int *bound_log2_x1000, int *prime_order) {
+    const group_vtable *vt = find_vt(curve, group);
+    if (!vt) return AMDMSM_ERR_UNSUPPORTED;
+    if (lambda_plain) memcpy(lambda_plain, vt->glv_lambda, (size_t)vt->fr_words * 4);
+    if (bound_log2_x1000) *bound_log2_x1000 = vt->glv_bound_log2_x1000;
+    if (prime_order) *prime_order = vt->prime_order;
     return AMDMSM_OK;
 }
 

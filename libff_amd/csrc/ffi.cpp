@@ -81,6 +81,7 @@ bool ffi_multiexp(int curve, int group, const void *bases, size_t bases_size, co
     o.out_form = AMDMSM_OUT_AFFINE;
     o.scalars_plain = 1;
     o.stream = st;
+    o.endomorphism = 1;   // a base outside the safe subgroup fails the call (status bit 4) whatever the MSM returns
     if (amdmsm_msm_device(ctx, curve, group, g_aff.p, g_sc.p, n, d_res, &o) != AMDMSM_OK) {
         (void)hipStreamSynchronize(st);
         return false;

@@ -68,6 +68,15 @@ struct group_vtable {
     int projective;    // libff stores this group in homogeneous projective coordinates
     int reduce_fold;   // segments / points one wave of reduce_segments / sum_butterfly folds (64 or 32)
     const uint32_t* fr_one_mont;   // Fr::one() in Montgomery form (R mod r), fr_words words
+    // endomorphism split k = k1 + k2 lambda (mod r), phi(x, y) = (beta x, y) = [lambda](x, y) on the
+    // order-r subgroup (msm_group.hip glv_split): |k1|, |k2| <= 2^(glv_bound_log2_x1000 / 1000)
+    int glv_bound_log2_x1000;
+    int prime_order;               // the whole curve group has order r (cofactor 1): phi = [lambda] everywhere
+    const uint32_t* glv_lambda;    // plain integer, fr_words words
+    // out[i] = phi(P_i) = (beta x_i, y_i), compact affine like the n bases
+    void (*endo_points)(hipStream_t, const uint32_t* bases_affine, size_t n, uint32_t* out);
+    // test hook: signed digits of both halves, out[(2 i + half) * W + w]
+    void (*glv_digits)(hipStream_t, const uint32_t* scalars, size_t n, int mont, int c, int W, int32_t* out);
 
     // libff (X, Y, Z) records -> compact affine (x, y); (0, 0) = infinity.
     // form_special != 0 promises Z == 1 or zero (multi_exp_base_form_special).
@@ -90,8 +99,13 @@ struct group_vtable {
     // first 4 zeroed (oversized coarse bins, sorted cooperatively); needs c <= 22
     void (*sort)(hipStream_t, const uint32_t* scalars, size_t n, int mont, int c, int W, uint32_t* coarse,
                  uint32_t* cursor, int32_t* digits, uint32_t* tmp_payload, uint32_t* tmp_key, uint32_t* ends,
-                 uint32_t* lists, size_t stride, uint32_t* big, int flat);
-    // flat != 0: the W digits of scalar i become entries i*W .. i*W+W-1 of ONE list over one
+                 uint32_t* lists, size_t stride, uint32_t* big, int mode, hipEvent_t after_coarse);
+    // after_coarse (may be null): recorded on the stream once the bandwidth-heavy first half (digit
+    // extraction, coarse partition) has been enqueued -- work queued behind it on another stream
+    // overlaps the LDS-bound fine pass
+    // mode 2: endomorphism split -- scalar i yields digit columns i (k1) and n + i (k2), so every
+    // per-column array is sized for 2n columns (stride >= 2n) and payloads >= n name phi(P_(e - n))
+    // mode 1 (flat): the W digits of scalar i become entries i*W .. i*W+W-1 of ONE list over one
     // bucket set (their payload indexes a precompute_table); then stride >= n*W, coarse / cursor /
     // ends are those of a single window and big is sized by sort_geometry(n*W, c, 1)
     // segmented bucket sums: lane t of window w owns list entries [t*S, (t+1)*S); buckets[]
@@ -100,7 +114,9 @@ struct group_vtable {
     // processed by passing offset pointers and its window count.
     void (*accumulate)(hipStream_t, const uint32_t* ends, const uint32_t* lists, size_t list_stride,
                        const uint32_t* bases_affine, uint32_t* buckets, uint32_t* part_first, uint32_t* part_last,
-                       uint32_t* cont_bucket, int W, uint32_t B, uint32_t S, uint32_t T);
+                       uint32_t* cont_bucket, int W, uint32_t B, uint32_t S, uint32_t T, const uint32_t* endo_points,
+                       size_t n_real);
+    // endo_points != null: list entries >= n_real name phi(P_(e - n_real)) = endo_points[e - n_real]
     // lanes of k_accumulate the device holds at once (CUs x resident workgroups x workgroup size)
     size_t (*accumulate_resident_lanes)();
     // closes the buckets that span several lanes; queue: fixup_queue_words(W*T) words, the

@@ -177,8 +177,8 @@ AMDMSM_DEV void store_out(uint32_t* q, const Jac<E>& p, int form) {
 // overflow (digit == 2^c) -> 0 with carry; bit c-1 set -> digit - 2^c with carry.
 // The scalar is streamed through a 64-bit bit buffer so no private array is
 // indexed at run time (which would send it to scratch).
-template <class F>
-AMDMSM_DEV void for_each_signed_digit(const uint32_t (&s)[FRW], int c, int W, F&& emit) {
+template <int NW, class F>
+AMDMSM_DEV void for_each_signed_digit(const uint32_t (&s)[NW], int c, int W, F&& emit) {
     const uint32_t mask = (1u << c) - 1u;
     uint64_t buf = 0;
     int nbits = 0;
@@ -194,7 +194,7 @@ AMDMSM_DEV void for_each_signed_digit(const uint32_t (&s)[FRW], int c, int W, F&
         ++w;
     };
 #pragma unroll
-    for (int j = 0; j < FRW; ++j) {
+    for (int j = 0; j < NW; ++j) {
         buf |= (uint64_t)s[j] << nbits;
         nbits += 32;
         while (nbits >= c && w < W) {
@@ -215,6 +215,87 @@ AMDMSM_DEV void load_scalar(uint32_t (&s)[FRW], const uint32_t* scalars, size_t 
     if (mont) fp_from_mont(x, x);   // Fp_model::as_bigint, multiexp.tcc:579-582
 #pragma unroll
     for (int j = 0; j < FRW; ++j) s[j] = x.v[j];
+}
+
+// ---------------------------------------------------------------- endomorphism split
+// k = k1 + k2 lambda (mod r) with |k1|, |k2| <= GLV::BOUND ~ sqrt(r) (constants and their
+// derivation: tools/gen_params.py glv_params; phi(x, y) = (beta x, y) = [lambda](x, y) on the
+// order-r subgroup).  The MSM over n points with Fr::num_bits-bit scalars becomes one over the 2n
+// points P_i, phi(P_i) with half-length scalars: same number of bucket entries, half the windows.
+using GLV = typename GP::glv;
+constexpr int GLV_HW = GLV::HW;       // limbs of |k1|, |k2|
+constexpr int GLV_HC = GLV::HW + 1;   // working width: two's complement with room for the sign
+
+// low GLV_HC limbs of (k G + 2^(s-1)) >> s, s = 32 (FRW + 1): Babai rounding of k b / r
+AMDMSM_DEV void glv_round_mul(uint32_t (&c)[GLV_HC], const uint32_t (&k)[FRW], const uint32_t (&G)[GLV::GW]) {
+    uint64_t carry = 0;
+#pragma unroll
+    for (int col = 0; col < FRW + 1 + GLV_HC; ++col) {
+        uint64_t lo = carry & 0xffffffffull, hi = carry >> 32;
+        if (col == FRW) lo += 0x80000000ull;
+#pragma unroll
+        for (int i = 0; i < FRW; ++i) {
+            const int j = col - i;
+            if (j >= 0 && j < GLV::GW) {
+                const uint64_t p = (uint64_t)k[i] * G[j];
+                lo += (uint32_t)p;
+                hi += p >> 32;
+            }
+        }
+        hi += lo >> 32;
+        if (col >= FRW + 1) c[col - FRW - 1] = (uint32_t)lo;
+        carry = hi;
+    }
+}
+// t = k (if ADD_K) + c1 * A + c2 * B  mod 2^(32 GLV_HC)
+template <bool ADD_K>
+AMDMSM_DEV void glv_combine(uint32_t (&t)[GLV_HC], const uint32_t (&k)[FRW], const uint32_t (&c1)[GLV_HC],
+                            const uint32_t (&A)[GLV_HC], const uint32_t (&c2)[GLV_HC], const uint32_t (&B)[GLV_HC]) {
+    uint64_t carry = 0;
+#pragma unroll
+    for (int col = 0; col < GLV_HC; ++col) {
+        uint64_t lo = carry & 0xffffffffull, hi = carry >> 32;
+        if (ADD_K && col < FRW) lo += k[col];
+#pragma unroll
+        for (int i = 0; i <= col; ++i) {
+            const uint64_t p = (uint64_t)c1[i] * A[col - i], q = (uint64_t)c2[i] * B[col - i];
+            lo += (uint64_t)(uint32_t)p + (uint32_t)q;
+            hi += (p >> 32) + (q >> 32);
+        }
+        hi += lo >> 32;
+        t[col] = (uint32_t)lo;
+        carry = hi;
+    }
+}
+// two's complement t -> (|t|, sign)
+AMDMSM_DEV bool glv_magnitude(uint32_t (&m)[GLV_HW], const uint32_t (&t)[GLV_HC]) {
+    const bool neg = (t[GLV_HC - 1] >> 31) != 0;
+    uint32_t carry = neg ? 1u : 0u;
+#pragma unroll
+    for (int i = 0; i < GLV_HW; ++i) {
+        const uint32_t v = neg ? ~t[i] : t[i];
+        m[i] = v + carry;
+        carry = (m[i] < v) ? 1u : 0u;
+    }
+    return neg;
+}
+AMDMSM_DEV void glv_split(const uint32_t (&k)[FRW], uint32_t (&m1)[GLV_HW], bool& neg1, uint32_t (&m2)[GLV_HW], bool& neg2) {
+    uint32_t c1[GLV_HC], c2[GLV_HC], t[GLV_HC];
+    glv_round_mul(c1, k, GLV::G1);
+    glv_round_mul(c2, k, GLV::G2);
+    glv_combine<true>(t, k, c1, GLV::M[0], c2, GLV::M[1]);
+    neg1 = glv_magnitude(m1, t);
+    glv_combine<false>(t, k, c1, GLV::M[2], c2, GLV::M[3]);
+    neg2 = glv_magnitude(m2, t);
+}
+// the two halves of scalar i, recoded: emit(half, w, d) -- half 0 belongs to P_i, half 1 to phi(P_i)
+template <class F>
+AMDMSM_DEV void for_each_glv_digit(const uint32_t (&k)[FRW], int c, int W, F&& emit) {
+    uint32_t m1[GLV_HW], m2[GLV_HW];
+    bool n1, n2;
+    glv_split(k, m1, n1, m2, n2);
+    for_each_signed_digit(m1, c, W, [&](int w, int32_t d) { emit(0, w, n1 ? -d : d); });
+    for_each_signed_digit(m2, c, W, [&](int w, int32_t d) { emit(1, w, n2 ? -d : d); });
 }
 
 // Histogram / cursor updates with wave-level aggregation of hot keys.  With uniformly random
@@ -296,6 +377,31 @@ __global__ void __launch_bounds__(TPB) k_digits(const uint32_t* __restrict__ sca
     uint32_t s[FRW];
     load_scalar(s, scalars, i, mont);
     for_each_signed_digit(s, c, W, [&](int w, int32_t d) { out[i * (size_t)W + w] = d; });
+}
+
+// test hook: out[(2 i + half) * W + w] = digit w of half `half` of scalar i
+__global__ void __launch_bounds__(TPB) k_glv_digits(const uint32_t* __restrict__ scalars, size_t n, int mont, int c, int W,
+                                                    int32_t* __restrict__ out) {
+    const size_t i = gtid();
+    if (i >= n) return;
+    uint32_t s[FRW];
+    load_scalar(s, scalars, i, mont);
+    for_each_glv_digit(s, c, W, [&](int h, int w, int32_t d) { out[(2 * i + h) * (size_t)W + w] = d; });
+}
+// phi(P_i) = (beta x_i, y_i) as compact affine records of their own (so that the accumulation
+// loop reads either kind of point as one contiguous record): one thread per Fq component
+__global__ void __launch_bounds__(TPB) k_endo_points(const uint32_t* __restrict__ bases, size_t n, uint32_t* __restrict__ out) {
+    const size_t t = gtid();
+    if (t >= n * 2 * GP::DEG) return;
+    const bool is_x = (t % (2 * GP::DEG)) < (size_t)GP::DEG;
+    Fp<FQ> v, beta;
+    fp_load(v, bases + t * FQ::N);
+    if (is_x) {
+#pragma unroll
+        for (int j = 0; j < FQ::N; ++j) beta.v[j] = GP::GLV_BETA[j];
+        fp_mul(v, v, beta);
+    }
+    fp_store(out + t * FQ::N, v);
 }
 
 // multi_exp_filter_one_zero's classification (multiexp.tcc:713-733: is_zero(), == FieldT::one())
@@ -441,10 +547,13 @@ AMDMSM_DEV uint32_t block_exclusive_scan(const uint32_t* cnt, uint32_t* out, uin
 
 __global__ void __launch_bounds__(SORT_TPB) k_sort_digits(const uint32_t* __restrict__ scalars, size_t n, int mont, int c,
                                                           int W, int hb, uint32_t per_block, int32_t* __restrict__ digits,
-                                                          size_t stride, uint32_t* __restrict__ coarse_counts, int flat) {
-    // flat: the W digits of scalar i are entries i*W .. i*W+W-1 of ONE list (they index a table
-    // of precomputed multiples [2^(jc)]P_i and share a single bucket set)
+                                                          size_t stride, uint32_t* __restrict__ coarse_counts, int mode) {
+    // mode 1 (flat): the W digits of scalar i are entries i*W .. i*W+W-1 of ONE list (they index a
+    // table of precomputed multiples [2^(jc)]P_i and share a single bucket set)
+    // mode 2 (endomorphism): scalar i gives two columns of W digits, i (k1, for P_i) and n + i
+    // (k2, for phi(P_i))
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];   // [W][2^hb]   (flat: [2^hb])
+    const bool flat = mode == 1;
     const uint32_t nbin = 1u << hb;
     const int fb = c - 1 - hb;
     const uint32_t nctr = flat ? nbin : (uint32_t)W * nbin;
@@ -456,13 +565,23 @@ __global__ void __launch_bounds__(SORT_TPB) k_sort_digits(const uint32_t* __rest
         if (i >= n) break;
         uint32_t s[FRW];
         load_scalar(s, scalars, i, mont);
-        for_each_signed_digit(s, c, W, [&](int w, int32_t d) {
-            digits[flat ? i * (size_t)W + w : (size_t)w * stride + i] = d;
-            if (d != 0) {
-                const uint32_t idx = (uint32_t)(d < 0 ? -d : d) - 1u;
-                atomicAdd(&smem[(flat ? 0u : (uint32_t)w * nbin) + (idx >> fb)], 1u);
-            }
-        });
+        if (mode == 2) {
+            for_each_glv_digit(s, c, W, [&](int h, int w, int32_t d) {
+                digits[(size_t)w * stride + (h ? n + i : i)] = d;
+                if (d != 0) {
+                    const uint32_t idx = (uint32_t)(d < 0 ? -d : d) - 1u;
+                    atomicAdd(&smem[(uint32_t)w * nbin + (idx >> fb)], 1u);
+                }
+            });
+        } else {
+            for_each_signed_digit(s, c, W, [&](int w, int32_t d) {
+                digits[flat ? i * (size_t)W + w : (size_t)w * stride + i] = d;
+                if (d != 0) {
+                    const uint32_t idx = (uint32_t)(d < 0 ? -d : d) - 1u;
+                    atomicAdd(&smem[(flat ? 0u : (uint32_t)w * nbin) + (idx >> fb)], 1u);
+                }
+            });
+        }
     }
     __syncthreads();
     for (uint32_t j = threadIdx.x; j < nctr; j += SORT_TPB) {
@@ -773,7 +892,10 @@ __global__ void __launch_bounds__(TPB, AMDMSM_ACC_WAVES) k_accumulate(const uint
                                                     size_t list_stride, const uint32_t* __restrict__ bases,
                                                     uint32_t* __restrict__ buckets, uint32_t* __restrict__ part_first,
                                                     uint32_t* __restrict__ part_last, uint32_t* __restrict__ cont_bucket,
-                                                    int W, uint32_t B, uint32_t S, uint32_t T) {
+                                                    int W, uint32_t B, uint32_t S, uint32_t T,
+                                                    const uint32_t* __restrict__ endo_pts, uint32_t n_real) {
+    // entries >= n_real (endomorphism split only; otherwise n_real = 2^31) name phi(P_(e - n_real)),
+    // record e - n_real of endo_pts (k_endo_points)
     const size_t g = gtid() / ACC_LANES;   // split form: lanes 2g, 2g+1 work on the same entries
     const size_t w = g / T;
     const uint32_t t = (uint32_t)(g % T);
@@ -806,8 +928,10 @@ __global__ void __launch_bounds__(TPB, AMDMSM_ACC_WAVES) k_accumulate(const uint
             } while (bend == k);   // skip empty buckets (k < total = e[B-1] bounds the walk)
         }
         const uint32_t ent = lst[k];
+        const uint32_t pi = ent & 0x7fffffffu;
+        const bool ph = pi >= n_real;
         Aff<EA> p;
-        load_aff(p, bases + (size_t)(ent & 0x7fffffffu) * AFFW);
+        load_aff(p, ph ? endo_pts + (size_t)(pi - n_real) * AFFW : bases + (size_t)pi * AFFW);
         el_cneg(p.y, p.y, (ent >> 31) != 0);   // -(x, y) = (x, -y); (0,0) stays infinity
 #if AMDMSM_ACC_LAZY
         xyzz_madd_lz(acc, p);   // coordinates of acc stay in [0, 2p) between stores
@@ -1744,10 +1868,12 @@ void l_scatter(hipStream_t st, const uint32_t* scalars, size_t n, int mont, int 
 // digits / lists may alias (digits are dead once k_sort_coarse has run)
 void l_sort(hipStream_t st, const uint32_t* scalars, size_t n, int mont, int c, int W, uint32_t* coarse,
             uint32_t* cursor, int32_t* digits, uint32_t* tmp_payload, uint32_t* tmp_key, uint32_t* ends, uint32_t* lists,
-            size_t stride, uint32_t* big, int flat) {
+            size_t stride, uint32_t* big, int mode, hipEvent_t after_coarse) {
     if (!n) return;
-    // flat: one list of n*W entries (entry i*W + j = digit j of scalar i), one bucket set
-    const size_t ne = flat ? n * (size_t)W : n;
+    // mode 1 (flat): one list of n*W entries (entry i*W + j = digit j of scalar i), one bucket set
+    // mode 2 (endomorphism split): 2n columns of W digits
+    const bool flat = mode == 1;
+    const size_t ne = flat ? n * (size_t)W : (mode == 2 ? 2 * n : n);
     const int We = flat ? 1 : W;
     const sort_geom sg = sort_geometry(ne, c, We);
     const int hb = sg.hb;
@@ -1756,10 +1882,11 @@ void l_sort(hipStream_t st, const uint32_t* scalars, size_t n, int mont, int c, 
     uint32_t per_block = 8192;
     while (per_block > SORT_TPB && (n + per_block - 1) / per_block < 1024) per_block >>= 1;
     hipLaunchKernelGGL(k_sort_digits, dim3((unsigned)((n + per_block - 1) / per_block)), dim3(SORT_TPB),
-                       (size_t)(flat ? 1 : W) * nbin * 4, st, scalars, n, mont, c, W, hb, per_block, digits, stride, coarse, flat);
+                       (size_t)(flat ? 1 : W) * nbin * 4, st, scalars, n, mont, c, W, hb, per_block, digits, stride, coarse, mode);
     hipLaunchKernelGGL(k_sort_scan, dim3(We), dim3(SORT_TPB), 0, st, coarse, cursor, nbin);
     hipLaunchKernelGGL(k_sort_coarse, dim3((unsigned)((ne + SORT_TILE - 1) / SORT_TILE), We), dim3(SORT_TPB), 0, st, digits,
                        ne, stride, c, hb, cursor, tmp_payload, tmp_key);
+    if (after_coarse) (void)hipEventRecord(after_coarse, st);
     const size_t fine_lds = ((size_t)4 << sg.fb) * 4 + (size_t)sg.chunk_cap * 6;
     if (sg.chunk_cap <= 4096)
         hipLaunchKernelGGL(k_sort_fine<256>, dim3(nbin, We), dim3(256), fine_lds, st, tmp_payload, tmp_key, coarse, stride,
@@ -1775,9 +1902,18 @@ void l_sort(hipStream_t st, const uint32_t* scalars, size_t n, int mont, int c, 
 }
 void l_accumulate(hipStream_t st, const uint32_t* ends, const uint32_t* lists, size_t list_stride, const uint32_t* bases,
                   uint32_t* buckets, uint32_t* part_first, uint32_t* part_last, uint32_t* cont_bucket, int W, uint32_t B,
-                  uint32_t S, uint32_t T) {
+                  uint32_t S, uint32_t T, const uint32_t* endo_pts, size_t n_real) {
     hipLaunchKernelGGL(k_accumulate, dim3(blocks_for((size_t)W * T * ACC_LANES)), dim3(TPB), 0, st, ends, lists, list_stride,
-                       bases, buckets, part_first, part_last, cont_bucket, W, B, S, T);
+                       bases, buckets, part_first, part_last, cont_bucket, W, B, S, T, endo_pts,
+                       endo_pts ? (uint32_t)n_real : 0x80000000u);
+}
+void l_endo_points(hipStream_t st, const uint32_t* bases, size_t n, uint32_t* out) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_endo_points, dim3(blocks_for(n * 2 * GP::DEG)), dim3(TPB), 0, st, bases, n, out);
+}
+void l_glv_digits(hipStream_t st, const uint32_t* scalars, size_t n, int mont, int c, int W, int32_t* out) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_glv_digits, dim3(blocks_for(n)), dim3(TPB), 0, st, scalars, n, mont, c, W, out);
 }
 size_t l_accumulate_resident_lanes() {
     static const size_t lanes = [] {
@@ -1897,6 +2033,7 @@ void l_madd_bench(hipStream_t st, const uint32_t* pts, uint32_t* out, size_t nth
 
 const group_vtable g_vt = {
     GP::CURVE, GP::GROUP, FRW, EW, FQ::N, FR::BITS, GP::LIBFF_PROJECTIVE ? 1 : 0, (int)RED_FOLD, FR::R,
+    GLV::BOUND_LOG2_X1000, GP::SUBGROUP_CHECK == 0 ? 1 : 0, GLV::LAMBDA, l_endo_points, l_glv_digits,
     l_import_bases, l_precompute_table, l_count, l_scatter, l_scalar_stats, l_sort, l_accumulate, l_accumulate_resident_lanes, l_accumulate_fixup, l_reduce_segments, l_sum_butterfly, l_horner, l_sum_points,
     l_gen_bases_seq, l_export_affine, l_ffi_decode_points, l_ffi_decode_scalars, l_ffi_encode_point, l_disk_decode, l_disk_decode_compressed, l_fixed_base_exp, l_field_op, l_group_op, l_digits, l_mul_bench, l_madd_bench,
 };

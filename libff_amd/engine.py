@@ -40,7 +40,8 @@ MAX_PHASES = 8
 
 EXPORTED_SYMBOLS = [
     "amdmsm_device_count", "amdmsm_ctx_create", "amdmsm_ctx_destroy", "amdmsm_strerror",
-    "amdmsm_last_error", "amdmsm_sizes", "amdmsm_plan", "amdmsm_pippenger_optimal_c",
+    "amdmsm_last_error", "amdmsm_sizes", "amdmsm_plan", "amdmsm_plan_ex", "amdmsm_endomorphism_info",
+    "amdmsm_endomorphism_digits_device", "amdmsm_pippenger_optimal_c",
     "amdmsm_bdlo12_signed_optimal_c", "amdmsm_multi_exp", "amdmsm_multi_exp_filter_one_zero",
     "amdmsm_multi_exp_multi", "amdmsm_msm_device_multi", "amdmsm_register_bases", "amdmsm_unregister_bases",
     "amdmsm_invalidate_bases",
@@ -64,7 +65,7 @@ class AmdMsmError(RuntimeError):
 
 class _Opts(ctypes.Structure):
     _fields_ = [("window_bits", ctypes.c_int), ("segment_len", ctypes.c_int), ("out_form", ctypes.c_int),
-                ("scalars_plain", ctypes.c_int), ("stream", ctypes.c_void_p)]
+                ("scalars_plain", ctypes.c_int), ("stream", ctypes.c_void_p), ("endomorphism", ctypes.c_int)]
 
 
 _lib = None
@@ -117,15 +118,28 @@ def sizes(curve, group):
     return {"fr_bytes": out[0], "g_bytes": out[1], "affine_bytes": out[2], "fr_bits": out[3]}
 
 
-def plan(curve, group, n, window_bits=0):
-    c, w = ctypes.c_int(0), ctypes.c_int(0)
+def plan(curve, group, n, window_bits=0, endomorphism=0):
+    c, w, used = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
     b = ctypes.c_uint32(0)
     ws = ctypes.c_size_t(0)
-    rc = load_library().amdmsm_plan(curve, group, ctypes.c_size_t(n), window_bits, ctypes.byref(c),
-                                    ctypes.byref(w), ctypes.byref(b), ctypes.byref(ws))
+    rc = load_library().amdmsm_plan_ex(curve, group, ctypes.c_size_t(n), window_bits, endomorphism, ctypes.byref(c),
+                                       ctypes.byref(w), ctypes.byref(b), ctypes.byref(ws), ctypes.byref(used))
     if rc:
-        raise AmdMsmError(f"amdmsm_plan: {rc}")
-    return {"c": c.value, "num_windows": w.value, "num_buckets": b.value, "workspace_bytes": ws.value}
+        raise AmdMsmError(f"amdmsm_plan_ex: {rc}")
+    return {"c": c.value, "num_windows": w.value, "num_buckets": b.value, "workspace_bytes": ws.value,
+            "endomorphism": bool(used.value)}
+
+
+def endomorphism_info(curve, group):
+    """lambda (int), log2 bound of the half scalars, whether the whole curve group has order r"""
+    s = sizes(curve, group)
+    lam = (ctypes.c_uint8 * s["fr_bytes"])()
+    bound, prime = ctypes.c_int(0), ctypes.c_int(0)
+    rc = load_library().amdmsm_endomorphism_info(curve, group, lam, ctypes.byref(bound), ctypes.byref(prime))
+    if rc:
+        raise AmdMsmError(f"amdmsm_endomorphism_info: {rc}")
+    return {"lambda": int.from_bytes(bytes(lam), "little"), "bound_log2": bound.value / 1000.0,
+            "prime_order": bool(prime.value)}
 
 
 def multi_exp_multi(engines, curve, group, bases, scalars, base_form=multi_exp_base_form_normal,
@@ -174,9 +188,10 @@ def _np_ptr(a):
 class Engine:
     """One amdmsm context (device, stream, workspace).  Fails loudly without a GPU."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, endomorphism=0):
         self.lib = load_library()
         self.device = device
+        self.endomorphism = endomorphism
         h = ctypes.c_void_p()
         rc = self.lib.amdmsm_ctx_create(device, ctypes.byref(h))
         if rc:
@@ -201,7 +216,9 @@ class Engine:
                                                       self.lib.amdmsm_last_error(self.h).decode()))
 
     def _opts(self, window_bits=0, segment_len=0, out_form=OUT_LIBFF, scalars_plain=False, stream=None):
-        return _Opts(window_bits, segment_len, out_form, int(scalars_plain), stream)
+        # self.endomorphism: amdmsm_opts.endomorphism for every call of this engine (0 = only where the
+        # whole curve group has order r, 1 = the bases are promised to lie in the order-r subgroup, -1 = off)
+        return _Opts(window_bits, segment_len, out_form, int(scalars_plain), stream, int(self.endomorphism))
 
     # ---------------------------------------------------------------- host API
     def multi_exp(self, curve, group, bases, scalars, method=multi_exp_method_BDLO12_signed,
@@ -556,6 +573,22 @@ class Engine:
             for p in (pa, pb, po):
                 if p is not None:
                     self.free(p)
+        return out
+
+    def endomorphism_digits(self, curve, group, scalars, c, num_windows, scalars_plain=False):
+        """device recoding of both halves of every scalar: int32 (n, 2, num_windows)"""
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint64)
+        n = scalars.shape[0]
+        out = np.zeros((n, 2, num_windows), dtype=np.int32)
+        ps, po = self._dev_arrays(scalars, out)
+        try:
+            self._check(self.lib.amdmsm_endomorphism_digits_device(self.h, curve, group, ps, ctypes.c_size_t(n),
+                                                                   int(scalars_plain), c, num_windows, po),
+                        "amdmsm_endomorphism_digits_device")
+            self.d2h(out, po)
+        finally:
+            self.free(ps)
+            self.free(po)
         return out
 
     def signed_digits(self, curve, scalars, c, num_windows, scalars_plain=False):

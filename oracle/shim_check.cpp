@@ -187,6 +187,12 @@ int main()
     if (const char *ms = std::getenv("SHIM_CHECK_MIN_SPLIT")) {
         libff_amd::min_points_per_device() = (size_t)std::atol(ms);
     }
+    // SHIM_CHECK_ENDOMORPHISM=<mode>: amdmsm_opts.endomorphism for every call (1: all groups may split
+    // their scalars -- the bases below are libff group elements, i.e. in the order-r subgroup)
+    if (const char *em = std::getenv("SHIM_CHECK_ENDOMORPHISM")) {
+        libff_amd::endomorphism_mode() = std::atoi(em);
+        printf("endomorphism mode %d\n", libff_amd::endomorphism_mode());
+    }
     inhibit_profiling_info = true;
     inhibit_profiling_counters = true;
     alt_bn128_pp::init_public_params();

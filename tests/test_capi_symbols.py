@@ -55,6 +55,9 @@ def test_sizes_and_plan_without_gpu(lib):
         assert s["affine_bytes"] == 2 * lit["coord_bytes"] and s["fr_bits"] == lit["fr_bits"]
         p = libff_amd.plan(curve, group, 1 << 20)
         assert p["num_buckets"] == 1 << (p["c"] - 1)
+        # (with the endomorphism split -- the default where the curve group has prime order -- the
+        # windows cover the half-length scalars instead: tests/test_endomorphism.py)
+        p = libff_amd.plan(curve, group, 1 << 20, endomorphism=-1)
         assert p["num_windows"] * p["c"] >= lit["fr_bits"] + 2
     for n, c in literal()["bdlo12_signed_optimal_c"].items():
         assert libff_amd.bdlo12_signed_optimal_c(int(n)) == c

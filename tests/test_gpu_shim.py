@@ -38,6 +38,19 @@ def test_template_shim_multi_device_route():
     assert r.returncode == 0 and "SHIM CHECK PASSED" in r.stdout
 
 
+@pytest.mark.gpu
+def test_template_shim_with_endomorphism_permitted():
+    """The same program with libff_amd::endomorphism_mode() = 1: G2 and the bls12_377 / bw6_761 groups
+    split their scalars too (their bases are libff group elements: in the order-r subgroup)."""
+    if not os.path.exists(BIN):
+        pytest.skip("oracle/_ref/shim_check not built (needs the reference sources at build time)")
+    env = dict(os.environ, SHIM_CHECK_ENDOMORPHISM="1", SHIM_CHECK_SKIP_LARGE="1")
+    r = subprocess.run([BIN], capture_output=True, text=True, timeout=900, env=env)
+    print(r.stdout[-3000:])
+    print(r.stderr[-2000:])
+    assert r.returncode == 0 and "SHIM CHECK PASSED" in r.stdout and "endomorphism mode 1" in r.stdout
+
+
 def test_shim_header_compiles_against_reference():
     """CPU-side: the header is valid C++11 against the reference headers (syntax + template
     selection); needs /root/reference and gmp.h, so it is skipped on the GPU box."""

@@ -136,6 +136,148 @@ def on_curve(q, g):
     return all((y2[i] - x3[i] - b[i]) % q == 0 for i in range(2))
 
 
+# ---------------------------------------------------------------- endomorphism (GLV) data
+# Every curve here is y^2 = x^3 + b (j = 0): phi(x, y) = (beta x, y), beta a primitive cube root
+# of unity in Fq, is an endomorphism, and on the order-r subgroup it acts as multiplication by a
+# cube root of unity lambda in Fr.  A scalar k splits as k = k1 + k2 lambda (mod r) with
+# |k1|, |k2| ~ sqrt(r) (Gallant-Lambert-Vanstone), so k P = k1 P + k2 phi(P): twice the points,
+# half the windows -- half the buckets to reduce and half the doublings of the final Horner pass.
+def _sqrt_mod(a, p):
+    a %= p
+    assert pow(a, (p - 1) // 2, p) == 1
+    q, s = p - 1, 0
+    while q % 2 == 0:
+        q //= 2
+        s += 1
+    z = 2
+    while pow(z, (p - 1) // 2, p) != p - 1:
+        z += 1
+    m, c, t, r = s, pow(z, q, p), pow(a, q, p), pow(a, (q + 1) // 2, p)
+    while t != 1:
+        i, tt = 0, t
+        while tt != 1:
+            tt = tt * tt % p
+            i += 1
+        b = pow(c, 1 << (m - i - 1), p)
+        m, c = i, b * b % p
+        t, r = t * c % p, r * b % p
+    return r
+
+
+def cube_roots_of_unity(p):
+    """the two roots of x^2 + x + 1 mod p, smaller first"""
+    s = _sqrt_mod(p - 3, p)
+    inv2 = pow(2, -1, p)
+    return sorted([(-1 + s) * inv2 % p, (-1 - s) * inv2 % p])
+
+
+def _ec(q, g):
+    """affine arithmetic on y^2 = x^3 + b over Fq or Fq2 (tuples of components); None = infinity"""
+    nr = g.get("nr", 0) % q
+    deg = g["deg"]
+
+    def mul(a, c):
+        if deg == 1:
+            return (a[0] * c[0] % q,)
+        return ((a[0] * c[0] + nr * a[1] * c[1]) % q, (a[0] * c[1] + a[1] * c[0]) % q)
+
+    def inv(a):
+        if deg == 1:
+            return (pow(a[0], -1, q),)
+        ni = pow((a[0] * a[0] - nr * a[1] * a[1]) % q, -1, q)
+        return (a[0] * ni % q, -a[1] * ni % q)
+
+    def sub(a, c):
+        return tuple((x - y) % q for x, y in zip(a, c))
+
+    def small(k):
+        return tuple([k % q] + [0] * (deg - 1))
+
+    def add(P, Q):
+        if P is None:
+            return Q
+        if Q is None:
+            return P
+        if P[0] == Q[0]:
+            if P[1] != Q[1] or all(v == 0 for v in P[1]):
+                return None
+            lam = mul(mul(small(3), mul(P[0], P[0])), inv(mul(small(2), P[1])))
+        else:
+            lam = mul(sub(Q[1], P[1]), inv(sub(Q[0], P[0])))
+        x = sub(sub(mul(lam, lam), P[0]), Q[0])
+        return (x, sub(mul(lam, sub(P[0], x)), P[1]))
+
+    def smul(k, P):
+        R = None
+        while k:
+            if k & 1:
+                R = add(R, P)
+            P = add(P, P)
+            k >>= 1
+        return R
+
+    return smul
+
+
+def glv_lattice(r, lam):
+    """two short vectors (a, b) with a + b lam = 0 (mod r): extended Euclid on (r, lam) stopped
+    around sqrt(r) (Guide to ECC, alg. 3.74)"""
+    from math import isqrt
+    a, b, t0, t1 = r, lam, 0, 1
+    seq = [(a, t0), (b, t1)]
+    while b:
+        qv = a // b
+        a, b = b, a - qv * b
+        t0, t1 = t1, t0 - qv * t1
+        seq.append((b, t1))
+    sq = isqrt(r)
+    l = max(i for i, (rem, _) in enumerate(seq) if rem >= sq)
+    v1 = (seq[l + 1][0], -seq[l + 1][1])
+    c1, c2 = (seq[l][0], -seq[l][1]), (seq[l + 2][0], -seq[l + 2][1])
+    v2 = c1 if c1[0] ** 2 + c1[1] ** 2 <= c2[0] ** 2 + c2[1] ** 2 else c2
+    return v1, v2
+
+
+def glv_params(cname):
+    """Everything the device needs to split a scalar, as plain integers.
+    c_i = floor((k G_i + 2^(s-1)) / 2^s), s = 32 (FRW + 1)       (Babai rounding, |error| < 2^-33)
+    k1 = k + c1 M11 + c2 M12,  k2 = c1 M21 + c2 M22               (signed, |k_j| <= bound)"""
+    from fractions import Fraction
+    c = CURVES[cname]
+    r, q = c["r"], c["q"]
+    frw = field(r)["n32"]
+    lam = cube_roots_of_unity(r)[0]
+    (a1, b1), (a2, b2) = glv_lattice(r, lam)
+    assert (a1 + b1 * lam) % r == 0 and (a2 + b2 * lam) % r == 0
+    det = a1 * b2 - a2 * b1
+    assert abs(det) == r
+    s = 32 * (frw + 1)
+    # (k, 0) = x1 v1 + x2 v2,  x1 = k b2 / det,  x2 = -k b1 / det
+    x = [Fraction(b2, det), Fraction(-b1, det)]
+    sg = [1 if v >= 0 else -1 for v in x]
+    G = [int(round(abs(v) * (1 << s))) for v in x]
+    M = [[-sg[0] * a1, -sg[1] * a2], [-sg[0] * b1, -sg[1] * b2]]
+    bound = max((abs(a1) + abs(a2)), (abs(b1) + abs(b2))) * ((1 << 32) + 1) // (1 << 33) + 1   # (1/2 + 2^-33) * sum
+    hw = (bound.bit_length() + 31) // 32
+    gw = (max(G).bit_length() + 31) // 32
+    betas = {}
+    for gname in ("g1", "g2"):
+        g = c[gname]
+        smul = _ec(q, g)
+        P = (tuple(v % q for v in g["x"]), tuple(v % q for v in g["y"]))
+        Q = smul(lam, P)
+        match = [beta for beta in cube_roots_of_unity(q) if Q == (tuple(v * beta % q for v in P[0]), P[1])]
+        assert len(match) == 1, (cname, gname)
+        betas[gname] = match[0]
+    return dict(lam=lam, s=s, G=G, M=M, bound=bound, hw=hw, gw=gw, cw=gw - 1, betas=betas, frw=frw)
+
+
+def glv_split(gp, k):
+    """the device's arithmetic on plain integers (tests use it to pin the constants)"""
+    c = [(k * gp["G"][i] + (1 << (gp["s"] - 1))) >> gp["s"] for i in range(2)]
+    return k + c[0] * gp["M"][0][0] + c[1] * gp["M"][0][1], c[0] * gp["M"][1][0] + c[1] * gp["M"][1][1]
+
+
 def c_arr(vals, fmt):
     return "{" + ", ".join(fmt % v for v in vals) + "}"
 
@@ -188,6 +330,26 @@ def emit_device_header():
     for cname, c in CURVES.items():
         emit_field(f"{cname}_fr", c["r"])
         emit_field(f"{cname}_fq", c["q"])
+    glv = {}
+    for cname, c in CURVES.items():
+        gp = glv[cname] = glv_params(cname)
+        hc = gp["hw"] + 1
+        import math
+        w(f"// k = k1 + k2 LAMBDA (mod r), |k1|, |k2| <= BOUND < 2^{gp['bound'].bit_length()}: see tools/gen_params.py glv_params")
+        w(f"struct {cname}_glv {{")
+        w(f"    static constexpr int HW = {gp['hw']};   // limbs of |k1|, |k2|")
+        w(f"    static constexpr int GW = {gp['gw']};   // limbs of G1, G2")
+        w(f"    static constexpr int CW = {gp['cw']};   // limbs of c_i = (k G_i + 2^(s-1)) >> s, s = 32 (fr::N + 1)")
+        w(f"    static constexpr int BOUND_LOG2_X1000 = {math.ceil(1000 * math.log2(gp['bound']))};   // ceil(1000 log2 BOUND)")
+        for i in range(2):
+            w(f"    static constexpr uint32_t G{i + 1}[{gp['gw']}] = {c_arr(limbs(gp['G'][i], gp['gw'], 32), '0x%08xu')};")
+        w("    // two's complement mod 2^(32 (HW + 1)):  k1 = k + c1 M[0] + c2 M[1],  k2 = c1 M[2] + c2 M[3]")
+        rows = [gp["M"][0][0], gp["M"][0][1], gp["M"][1][0], gp["M"][1][1]]
+        w(f"    static constexpr uint32_t M[4][{hc}] = {{" +
+          ", ".join(c_arr(limbs(v % (1 << (32 * hc)), hc, 32), "0x%08xu") for v in rows) + "};")
+        w(f"    static constexpr uint32_t LAMBDA[{gp['frw']}] = {c_arr(limbs(gp['lam'], gp['frw'], 32), '0x%08xu')};   // plain integer")
+        w("};")
+        w("")
     for cname, c in CURVES.items():
         fq = field(c["q"])
         for gname in ("g1", "g2"):
@@ -198,6 +360,10 @@ def emit_device_header():
             w(f"struct {cname}_{gname} {{")
             w(f"    using fq = {cname}_fq;")
             w(f"    using fr = {cname}_fr;")
+            w(f"    using glv = {cname}_glv;")
+            w(f"    static constexpr uint32_t GLV_BETA[{fq['n32']}] = "
+              f"{c_arr(limbs(glv[cname]['betas'][gname] * fq['R'] % c['q'], fq['n32'], 32), '0x%08xu')};"
+              "   // phi(x, y) = (BETA x, y) = [LAMBDA](x, y) on the order-r subgroup; Montgomery form")
             w(f"    static constexpr int CURVE = {c['id']};")
             w(f"    static constexpr int GROUP = {1 if gname == 'g1' else 2};")
             w(f"    static constexpr int DEG = {deg};           // coordinate field = Fq^DEG")

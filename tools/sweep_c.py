@@ -20,10 +20,11 @@ def main():
     ap.add_argument("--segment-len", type=int, default=0)
     ap.add_argument("--repeat-frac", type=float, default=0.0,
                     help="fraction of the scalars replaced by ONE repeated random value (heavy-hitter buckets)")
+    ap.add_argument("--endo", type=int, default=0, help="amdmsm_opts.endomorphism: 0 auto, 1 on, -1 off")
     args = ap.parse_args()
     curve, group = CURVES[args.curve], args.group
     dev = torch.device("cuda", 0)
-    eng = libff_amd.Engine(0)
+    eng = libff_amd.Engine(0, endomorphism=args.endo)
     eng.set_timing(True)
     sz = libff_amd.sizes(curve, group)
     out = torch.zeros(sz["g_bytes"] // 8, dtype=torch.int64, device=dev)
@@ -38,7 +39,7 @@ def main():
             scalars[idx] = scalars[0].clone()
         torch.cuda.synchronize()
         for c in args.c:
-            p = libff_amd.plan(curve, group, n, c)
+            p = libff_amd.plan(curve, group, n, c, endomorphism=args.endo)
             best = None
             for _ in range(3):
                 eng.msm_device(curve, group, bases.data_ptr(), scalars.data_ptr(), n, out.data_ptr(),
@@ -47,8 +48,8 @@ def main():
                 t = eng.get_timings()
                 if best is None or t["total_ms"] < best["total_ms"]:
                     best = t
-            madds = n * p["num_windows"]
-            print(f"n=2^{L} c={p['c']:2d} W={p['num_windows']:2d} total={best['total_ms']:9.3f} ms "
+            madds = n * p["num_windows"] * (2 if p["endomorphism"] else 1)
+            print(f"n=2^{L} {'endo' if p['endomorphism'] else 'full'} c={p['c']:2d} W={p['num_windows']:2d} total={best['total_ms']:9.3f} ms "
                   f"count={best['count_ms']:7.3f} scatter={best['scatter_ms']:7.3f} accum={best['accumulate_ms']:8.3f} "
                   f"reduce={best['reduce_ms']:7.3f} final={best['final_ms']:6.3f}  "
                   f"{n / best['total_ms'] / 1e3:8.2f} M pts/s  accum {madds / best['accumulate_ms'] / 1e6:6.3f} G madd/s",
