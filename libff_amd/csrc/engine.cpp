@@ -499,8 +499,13 @@ int msm_device_impl(amdmsm_ctx *ctx, const group_vtable *vt, const uint32_t *d_b
         uint32_t M = (uint32_t)M0;
         M /= std::min<uint32_t>(M, fold);   // folded per wave inside reduce_segments
         while (M > 1) {
-            vt->sum_butterfly(ts, src, wg, M, dst);
-            M /= std::min<uint32_t>(M, fold);
+            if ((size_t)M * (64 / fold) <= 256) {   // the remaining levels in one launch
+                vt->sum_block(ts, src, wg, M, dst);
+                M = 1;
+            } else {
+                vt->sum_butterfly(ts, src, wg, M, dst);
+                M /= std::min<uint32_t>(M, fold);
+            }
             std::swap(src, dst);
         }
         // Horner over this group's windows, continuing from the groups above

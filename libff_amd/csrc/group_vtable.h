@@ -129,6 +129,8 @@ struct group_vtable {
     void (*reduce_segments)(hipStream_t, const uint32_t* buckets, int W, uint32_t B, uint32_t L, uint32_t* out);
     // out[w][g] = sum_{i in [g*G, (g+1)*G)} in[w][i], G = min(M, reduce_fold)
     void (*sum_butterfly)(hipStream_t, const uint32_t* in, int W, uint32_t M, uint32_t* out);
+    // out[w] = sum_i in[w][i], i < M, one workgroup per window; M * (64 / reduce_fold) <= 256
+    void (*sum_block)(hipStream_t, const uint32_t* in, int W, uint32_t M, uint32_t* out);
     // Horner over window sums (high to low, c doublings between), write one point; init (engine
     // Jacobian, may be null) = value carried in from the windows above window_sums[W-1]
     void (*horner)(hipStream_t, const uint32_t* window_sums, int W, int c, int form, const uint32_t* init,

@@ -910,6 +910,10 @@ __global__ void __launch_bounds__(TPB, AMDMSM_ACC_WAVES) k_accumulate(const uint
     const uint32_t hi = (lo + S < total) ? lo + S : total;
     uint32_t b = bucket_of_entry(e, B, lo);
     uint32_t bend = e[b];
+    // end of the bucket after the current one, fetched a whole bucket ahead: closing a bucket then
+    // needs no load (a dependent global load there stalls the 64 lanes of the wave about once per
+    // iteration when buckets hold ~S entries)
+    uint32_t bnext = b + 1 < B ? e[b + 1] : 0xffffffffu;
     bool from_prev = (b ? e[b - 1] : 0u) < lo;   // first piece continues a bucket begun earlier
     const uint32_t* lst = lists + w * list_stride;
     uint32_t* bk = buckets + w * (size_t)B * ZZW;
@@ -924,7 +928,8 @@ __global__ void __launch_bounds__(TPB, AMDMSM_ACC_WAVES) k_accumulate(const uint
             xyzz_set_inf(acc);
             do {
                 ++b;
-                bend = e[b];
+                bend = bnext;
+                bnext = b + 1 < B ? e[b + 1] : 0xffffffffu;
             } while (bend == k);   // skip empty buckets (k < total = e[B-1] bounds the walk)
         }
         const uint32_t ent = lst[k];
@@ -1168,6 +1173,29 @@ __global__ void __launch_bounds__(64) k_sum_butterfly(const uint32_t* __restrict
     if (valid) load_jac(p, in + t * XYZW); else jac_set_inf(p);
     wave_group_sum_r(p, G);
     if (valid && (i % G) == 0) store_jac(out + (w * (M / G) + i / G) * XYZW, p);
+}
+
+// The last levels of the plain sums in one launch: one workgroup per window folds its M <=
+// 256 / RED_LANES points -- every wave its RED_FOLD, then the first wave the per-wave results
+// (through LDS) -- instead of a launch (and a lone-wave addition chain) per level.  out[w].
+__global__ void __launch_bounds__(256) k_sum_block(const uint32_t* __restrict__ in, int W, uint32_t M,
+                                                    uint32_t* __restrict__ out) {
+    __shared__ uint32_t part[4 * XYZW];
+    const size_t w = blockIdx.x;
+    const uint32_t i = threadIdx.x / RED_LANES;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    Jac<ER> p;
+    if (i < M) load_jac(p, in + (w * M + i) * XYZW); else jac_set_inf(p);
+    wave_group_sum_r(p, RED_FOLD);
+    if (lane < (uint32_t)RED_LANES) store_jac(part + wave * XYZW, p);
+    __syncthreads();
+    if (wave != 0) return;
+    const uint32_t j = lane / RED_LANES;
+    if (j < nw) load_jac(p, part + j * XYZW); else jac_set_inf(p);
+    uint32_t G = 1;
+    while (G < nw) G <<= 1;
+    wave_group_sum_r(p, G);
+    if (lane < (uint32_t)RED_LANES) store_jac(out + w * XYZW, p);
 }
 
 // Horner over the window sums, high to low, c doublings between windows (multiexp.tcc:612-629),
@@ -1946,6 +1974,10 @@ void l_reduce_segments(hipStream_t st, const uint32_t* buckets, int W, uint32_t 
 void l_sum_butterfly(hipStream_t st, const uint32_t* in, int W, uint32_t M, uint32_t* out) {
     hipLaunchKernelGGL(k_sum_butterfly, dim3(blocks_for((size_t)W * M * RED_LANES, 64)), dim3(64), 0, st, in, W, M, out);
 }
+void l_sum_block(hipStream_t st, const uint32_t* in, int W, uint32_t M, uint32_t* out) {
+    const unsigned threads = (unsigned)((M * RED_LANES + 63) / 64 * 64);
+    hipLaunchKernelGGL(k_sum_block, dim3(W), dim3(threads), 0, st, in, W, M, out);
+}
 void l_horner(hipStream_t st, const uint32_t* window_sums, int W, int c, int form, const uint32_t* init, uint32_t* out) {
     hipLaunchKernelGGL(k_horner, dim3(1), dim3(64), 0, st, window_sums, W, c, form, init, out);
 }
@@ -2034,7 +2066,7 @@ void l_madd_bench(hipStream_t st, const uint32_t* pts, uint32_t* out, size_t nth
 const group_vtable g_vt = {
     GP::CURVE, GP::GROUP, FRW, EW, FQ::N, FR::BITS, GP::LIBFF_PROJECTIVE ? 1 : 0, (int)RED_FOLD, FR::R,
     GLV::BOUND_LOG2_X1000, GP::SUBGROUP_CHECK == 0 ? 1 : 0, GLV::LAMBDA, l_endo_points, l_glv_digits,
-    l_import_bases, l_precompute_table, l_count, l_scatter, l_scalar_stats, l_sort, l_accumulate, l_accumulate_resident_lanes, l_accumulate_fixup, l_reduce_segments, l_sum_butterfly, l_horner, l_sum_points,
+    l_import_bases, l_precompute_table, l_count, l_scatter, l_scalar_stats, l_sort, l_accumulate, l_accumulate_resident_lanes, l_accumulate_fixup, l_reduce_segments, l_sum_butterfly, l_sum_block, l_horner, l_sum_points,
     l_gen_bases_seq, l_export_affine, l_ffi_decode_points, l_ffi_decode_scalars, l_ffi_encode_point, l_disk_decode, l_disk_decode_compressed, l_fixed_base_exp, l_field_op, l_group_op, l_digits, l_mul_bench, l_madd_bench,
 };
 
