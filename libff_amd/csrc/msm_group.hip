@@ -934,9 +934,8 @@ __global__ void __launch_bounds__(TPB, AMDMSM_ACC_WAVES) k_accumulate(const uint
         }
         const uint32_t ent = lst[k];
         const uint32_t pi = ent & 0x7fffffffu;
-        const bool ph = pi >= n_real;
         Aff<EA> p;
-        load_aff(p, ph ? endo_pts + (size_t)(pi - n_real) * AFFW : bases + (size_t)pi * AFFW);
+        load_aff(p, pi >= n_real ? endo_pts + (size_t)(pi - n_real) * AFFW : bases + (size_t)pi * AFFW);
         el_cneg(p.y, p.y, (ent >> 31) != 0);   // -(x, y) = (x, -y); (0,0) stays infinity
 #if AMDMSM_ACC_LAZY
         xyzz_madd_lz(acc, p);   // coordinates of acc stay in [0, 2p) between stores
