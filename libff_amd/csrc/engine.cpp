@@ -262,7 +262,7 @@ int make_plan(const group_vtable *vt, size_t n, int c_req, int L_req, plan_t &p,
     if (L == 0 || (L & (L - 1))) return AMDMSM_ERR_BAD_ARG;
     p.L = L;
     const size_t xyz_bytes = (size_t)3 * vt->el_words * 4;
-    p.list_stride = align_up(n ? n : 1, 64);
+    p.list_stride = align_up(n ? n : 1, 64) + 16;   // + one chunk: a lane's last staged read may run past its entries
     // entries per lane S (<= 128; lane t of a window owns entries [t*S, (t+1)*S)).  All lanes do the
     // same work and the device holds `resident` of them at once, so the lane count W*T should
     // fill whole rounds: k rounds exactly for the smallest k that keeps S <= 128, or simply

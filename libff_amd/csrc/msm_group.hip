@@ -919,7 +919,22 @@ __global__ void __launch_bounds__(TPB, AMDMSM_ACC_WAVES) k_accumulate(const uint
     uint32_t* bk = buckets + w * (size_t)B * ZZW;
     Xyzz<EA> acc;
     xyzz_set_inf(acc);
+    // The lane's list entries are staged through LDS sixteen at a time (sixteen loads issued
+    // together, once per sixteen iterations): read one word per iteration, the 256 lanes of a
+    // workgroup touch 256 different cache lines every iteration, the point gathers evict them in
+    // between, and every line is fetched again for each of its entries (measured: half of the
+    // kernel's memory traffic).  The last chunk of a lane may read up to 15 entries past its
+    // range: the list allocation carries that much slack (make_plan).
+    __shared__ uint32_t staged[16 * TPB];   // [entry in chunk][thread]: conflict-free both ways
     for (uint32_t k = lo; k < hi; ++k) {
+        const uint32_t kk = (k - lo) & 15u;
+        if (kk == 0) {
+            uint32_t v[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) v[q] = lst[k + q];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) staged[q * TPB + threadIdx.x] = v[q];
+        }
         if (k == bend) {
             // bucket b ends here: it is complete unless its head lies in an earlier lane
             xyzz_canon(acc);
@@ -932,7 +947,7 @@ __global__ void __launch_bounds__(TPB, AMDMSM_ACC_WAVES) k_accumulate(const uint
                 bnext = b + 1 < B ? e[b + 1] : 0xffffffffu;
             } while (bend == k);   // skip empty buckets (k < total = e[B-1] bounds the walk)
         }
-        const uint32_t ent = lst[k];
+        const uint32_t ent = staged[kk * TPB + threadIdx.x];
         const uint32_t pi = ent & 0x7fffffffu;
         Aff<EA> p;
         load_aff(p, pi >= n_real ? endo_pts + (size_t)(pi - n_real) * AFFW : bases + (size_t)pi * AFFW);
