@@ -317,7 +317,7 @@ int make_plan(const group_vtable *vt, size_t n, int c_req, int L_req, plan_t &p,
     p.off_tmp_payload = off;
     off = align_up(off + (size_t)p.W * p.list_stride * 4, 256);
     p.off_tmp_key = off;
-    off = align_up(off + (size_t)p.W * p.list_stride * 4, 256);
+    off = align_up(off + (size_t)p.W * p.list_stride * 4, 256);   // 16-bit fine keys use half of it
     p.off_big = off;
     if (p.c <= 22) off = align_up(off + sort_geometry(n, p.c, p.W).big_words * 4, 256);
     p.off_endo = off;

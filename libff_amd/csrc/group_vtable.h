@@ -94,8 +94,8 @@ struct group_vtable {
     // classification, multiexp.tcc:713-733); mont: the scalars are Montgomery residues
     void (*scalar_stats)(hipStream_t, const uint32_t* scalars, size_t n, int mont, uint32_t* stats);
     // LDS-staged two-level sort (same result as count + scatter): ends[w][b] and lists[w][...].
-    // coarse: W*(2^hb+1) words zeroed, cursor: W*2^hb words, digits/tmp_payload/tmp_key/lists:
-    // W*stride words each (digits may alias lists); big: sort_geometry().big_words words, the
+    // coarse: W*(2^hb+1) words zeroed, cursor: W*2^hb words, digits/tmp_payload/lists:
+    // W*stride words each (digits may alias lists), tmp_key: W*stride 16-bit fine keys; big: sort_geometry().big_words words, the
     // first 4 zeroed (oversized coarse bins, sorted cooperatively); needs c <= 22
     void (*sort)(hipStream_t, const uint32_t* scalars, size_t n, int mont, int c, int W, uint32_t* coarse,
                  uint32_t* cursor, int32_t* digits, uint32_t* tmp_payload, uint32_t* tmp_key, uint32_t* ends,

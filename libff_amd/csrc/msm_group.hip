@@ -498,6 +498,14 @@ constexpr int SORT_TPB = 1024;
 #ifndef AMDMSM_SORT_TILE
 #define AMDMSM_SORT_TILE 16384
 #endif
+#ifndef AMDMSM_SORT_KEY32
+#define AMDMSM_SORT_KEY32 0
+#endif
+#if AMDMSM_SORT_KEY32
+using sort_key_t = uint32_t;
+#else
+using sort_key_t = unsigned short;   // fine part of the bucket index between the two sort levels
+#endif
 constexpr int SORT_TILE = AMDMSM_SORT_TILE;    // entries per k_sort_coarse workgroup
 constexpr int SORT_CHUNK = 16384;   // entries per k_sort_fine chunk
 constexpr int SORT_MAX_HB = 10;
@@ -608,7 +616,8 @@ __global__ void __launch_bounds__(SORT_TPB) k_sort_scan(uint32_t* __restrict__ c
 __global__ void __launch_bounds__(SORT_TPB) k_sort_coarse(const int32_t* __restrict__ digits, size_t n, size_t stride, int c,
                                                           int hb, uint32_t* __restrict__ cursor,
                                                           uint32_t* __restrict__ tmp_payload,
-                                                          uint32_t* __restrict__ tmp_key) {
+                                                          sort_key_t* __restrict__ tmp_key) {
+    // tmp_key: the fine part of the bucket index (fb <= 11 bits) -- all the second level needs
     __shared__ uint32_t hist[1 << SORT_MAX_HB], lstart[1 << SORT_MAX_HB], lcur[1 << SORT_MAX_HB], tmp[SORT_TPB / 64 + 1];
     __shared__ uint32_t st_payload[SORT_TILE], st_key[SORT_TILE];
     uint32_t* gbase = hist;   // hist[j] is dead once slot j's global base has been reserved
@@ -650,7 +659,7 @@ __global__ void __launch_bounds__(SORT_TPB) k_sort_coarse(const int32_t* __restr
         const uint32_t bin = key >> fb;
         const size_t pos = (size_t)w * stride + gbase[bin] + (k - lstart[bin]);
         tmp_payload[pos] = st_payload[k];
-        tmp_key[pos] = key;
+        tmp_key[pos] = (sort_key_t)(key & ((1u << fb) - 1u));
     }
 }
 
@@ -658,7 +667,7 @@ __global__ void __launch_bounds__(SORT_TPB) k_sort_coarse(const int32_t* __restr
 // a few thousand at most (2^20-point inputs), where barriers between 16 waves would dominate
 template <int NT>
 __global__ void __launch_bounds__(NT) k_sort_fine(const uint32_t* __restrict__ tmp_payload,
-                                                        const uint32_t* __restrict__ tmp_key,
+                                                        const sort_key_t* __restrict__ tmp_key,
                                                         const uint32_t* __restrict__ coarse, size_t stride, int c, int hb,
                                                         uint32_t chunk_cap, uint32_t big_thresh, uint32_t big_cap,
                                                         uint32_t* __restrict__ big, uint32_t* __restrict__ ends,
@@ -678,7 +687,7 @@ __global__ void __launch_bounds__(NT) k_sort_fine(const uint32_t* __restrict__ t
     const uint32_t bin = blockIdx.x, w = blockIdx.y;
     const uint32_t* cs = coarse + (size_t)w * (nbin + 1);
     const uint32_t b0 = cs[bin], m = cs[bin + 1] - b0;
-    const uint32_t* key = tmp_key + (size_t)w * stride + b0;
+    const sort_key_t* key = tmp_key + (size_t)w * stride + b0;
     const uint32_t* pay = tmp_payload + (size_t)w * stride + b0;
     uint32_t* out = lists + (size_t)w * stride + b0;
     uint32_t* e = ends + (((size_t)w << (c - 1)) + ((size_t)bin << fb));
@@ -762,7 +771,7 @@ AMDMSM_DEV bool big_find_tile(const uint32_t* __restrict__ big, const uint32_t* 
     return true;
 }
 
-__global__ void __launch_bounds__(SORT_TPB) k_sort_big_hist(const uint32_t* __restrict__ tmp_key,
+__global__ void __launch_bounds__(SORT_TPB) k_sort_big_hist(const sort_key_t* __restrict__ tmp_key,
                                                             const uint32_t* __restrict__ coarse, size_t stride, int c,
                                                             int hb, const uint32_t* __restrict__ big,
                                                             uint32_t* __restrict__ ends) {
@@ -777,7 +786,7 @@ __global__ void __launch_bounds__(SORT_TPB) k_sort_big_hist(const uint32_t* __re
         big_find_tile(big, coarse, nbin, tile, sh, bt, b0);
         for (uint32_t j = threadIdx.x; j < nfine; j += SORT_TPB) hist[j] = 0;
         __syncthreads();
-        const uint32_t* key = tmp_key + (size_t)bt.w * stride + b0 + bt.k0;
+        const sort_key_t* key = tmp_key + (size_t)bt.w * stride + b0 + bt.k0;
         for (uint32_t k = threadIdx.x; k < bt.cm; k += SORT_TPB) atomicAdd(&hist[key[k] & fmask], 1u);
         __syncthreads();
         uint32_t* e = ends + (((size_t)bt.w << (c - 1)) + ((size_t)bt.bin << fb));
@@ -812,7 +821,7 @@ __global__ void __launch_bounds__(SORT_TPB) k_sort_big_scan(const uint32_t* __re
 }
 
 __global__ void __launch_bounds__(SORT_TPB) k_sort_big_scatter(const uint32_t* __restrict__ tmp_payload,
-                                                               const uint32_t* __restrict__ tmp_key,
+                                                               const sort_key_t* __restrict__ tmp_key,
                                                                const uint32_t* __restrict__ coarse, size_t stride, int c,
                                                                int hb, uint32_t big_cap, uint32_t* __restrict__ big,
                                                                uint32_t* __restrict__ lists) {
@@ -835,7 +844,7 @@ __global__ void __launch_bounds__(SORT_TPB) k_sort_big_scatter(const uint32_t* _
         big_find_tile(big, coarse, nbin, tile, sh, bt, b0);
         for (uint32_t j = threadIdx.x; j < nfine; j += SORT_TPB) hist[j] = 0;
         __syncthreads();
-        const uint32_t* key = tmp_key + (size_t)bt.w * stride + b0 + bt.k0;
+        const sort_key_t* key = tmp_key + (size_t)bt.w * stride + b0 + bt.k0;
         const uint32_t* pay = tmp_payload + (size_t)bt.w * stride + b0 + bt.k0;
         for (uint32_t k = threadIdx.x; k < bt.cm; k += SORT_TPB) atomicAdd(&hist[key[k] & fmask], 1u);
         __syncthreads();
@@ -1926,20 +1935,21 @@ void l_sort(hipStream_t st, const uint32_t* scalars, size_t n, int mont, int c, 
     hipLaunchKernelGGL(k_sort_digits, dim3((unsigned)((n + per_block - 1) / per_block)), dim3(SORT_TPB),
                        (size_t)(flat ? 1 : W) * nbin * 4, st, scalars, n, mont, c, W, hb, per_block, digits, stride, coarse, mode);
     hipLaunchKernelGGL(k_sort_scan, dim3(We), dim3(SORT_TPB), 0, st, coarse, cursor, nbin);
+    sort_key_t* tmp_key16 = reinterpret_cast<sort_key_t*>(tmp_key);   // W * stride fine keys
     hipLaunchKernelGGL(k_sort_coarse, dim3((unsigned)((ne + SORT_TILE - 1) / SORT_TILE), We), dim3(SORT_TPB), 0, st, digits,
-                       ne, stride, c, hb, cursor, tmp_payload, tmp_key);
+                       ne, stride, c, hb, cursor, tmp_payload, tmp_key16);
     if (after_coarse) (void)hipEventRecord(after_coarse, st);
     const size_t fine_lds = ((size_t)4 << sg.fb) * 4 + (size_t)sg.chunk_cap * 6;
     if (sg.chunk_cap <= 4096)
-        hipLaunchKernelGGL(k_sort_fine<256>, dim3(nbin, We), dim3(256), fine_lds, st, tmp_payload, tmp_key, coarse, stride,
+        hipLaunchKernelGGL(k_sort_fine<256>, dim3(nbin, We), dim3(256), fine_lds, st, tmp_payload, tmp_key16, coarse, stride,
                            c, hb, sg.chunk_cap, sg.big_thresh, sg.big_cap, big, ends, lists);
     else
-        hipLaunchKernelGGL(k_sort_fine<SORT_TPB>, dim3(nbin, We), dim3(SORT_TPB), fine_lds, st, tmp_payload, tmp_key, coarse,
+        hipLaunchKernelGGL(k_sort_fine<SORT_TPB>, dim3(nbin, We), dim3(SORT_TPB), fine_lds, st, tmp_payload, tmp_key16, coarse,
                            stride, c, hb, sg.chunk_cap, sg.big_thresh, sg.big_cap, big, ends, lists);
-    hipLaunchKernelGGL(k_sort_big_hist, dim3(2048), dim3(SORT_TPB), 0, st, tmp_key, coarse, stride, c, hb, big, ends);
+    hipLaunchKernelGGL(k_sort_big_hist, dim3(2048), dim3(SORT_TPB), 0, st, tmp_key16, coarse, stride, c, hb, big, ends);
     hipLaunchKernelGGL(k_sort_big_scan, dim3(256), dim3(SORT_TPB), 0, st, coarse, c, hb, sg.big_cap, big, ends);
     const size_t big_lds = ((size_t)4 << sg.fb) * 4 + (size_t)SORT_TILE * 6;
-    hipLaunchKernelGGL(k_sort_big_scatter, dim3(2048), dim3(SORT_TPB), big_lds, st, tmp_payload, tmp_key, coarse, stride, c,
+    hipLaunchKernelGGL(k_sort_big_scatter, dim3(2048), dim3(SORT_TPB), big_lds, st, tmp_payload, tmp_key16, coarse, stride, c,
                        hb, sg.big_cap, big, lists);
 }
 void l_accumulate(hipStream_t st, const uint32_t* ends, const uint32_t* lists, size_t list_stride, const uint32_t* bases,
