@@ -172,10 +172,10 @@ int num_windows(const group_vtable *vt, int c, bool glv) { return glv ? glv_wind
 // the endomorphism split.  The split doubles the digit columns and halves their length: about the
 // same number of bucket entries, half the buckets to reduce and half the final doublings
 // (~1.95 us each) -- measured on alt_bn128 G1 2^16 / 2^18 / 2^20 / 2^21 points: 1.02 vs 1.34,
-// 1.34 vs 1.71, 2.66 vs 2.98, 4.64 vs 4.72 ms; its entries cost ~3 % more below 2^22 points (x and
-// y of phi(P) come from two arrays) and ~8 % more above, where the base loads miss the caches, so
-// from 2^22 points up the plain path is ahead again (2^23: 15.1 vs 14.5, 2^26: 94.4 vs 92.1 ms;
-// profiles/r02_endomorphism_sweep.txt).
+// 1.34 vs 1.71, 2.66 vs 2.98, 4.38 vs 4.56 ms; its entries cost the same below 2^22 points and ~8 %
+// more above, where bases plus phi(P) records (2 x 64 B x n) no longer fit the 256 MB Infinity
+// Cache, so from 2^22 points up the plain path is level or ahead again (2^22: 7.78 vs 7.84,
+// 2^23: 14.0 vs 13.7, 2^26: 87.4 vs 87.6 ms; profiles/r02_endomorphism_sweep.txt).
 double plan_cost(const group_vtable *vt, size_t n, int c, bool glv) {
     const int bits = glv ? (vt->glv_bound_log2_x1000 + 999) / 1000 : vt->fr_bits;
     const int W = num_windows(vt, c, glv);
@@ -185,7 +185,7 @@ double plan_cost(const group_vtable *vt, size_t n, int c, bool glv) {
     // while an accumulation entry costs 8.3x)
     const double wide = vt->fq_words >= 24 ? 2.2 : ((vt->fq_words > 8 || vt->el_words > vt->fq_words) ? 1.5 : 1.0);
     // (the wider fields hide the second base load behind their longer additions: same rate either way)
-    const double entry = !glv ? 1.0 : (n < ((size_t)1 << 22) ? (wide > 1.0 ? 1.0 : 1.03) : (wide > 1.0 ? 1.02 : 1.08));
+    const double entry = !glv ? 1.0 : (n < ((size_t)1 << 22) ? 1.0 : (wide > 1.0 ? 1.02 : 1.08));
     const bool large = n >= ((size_t)1 << 23);
     // windows that can hold a nonzero digit: with W * c well above the scalar length the top
     // window sees neither a scalar bit nor the carry (c = 17: 15 of 16 windows for a 254-bit
