@@ -715,14 +715,19 @@ __global__ void __launch_bounds__(NT) k_sort_fine(const uint32_t* __restrict__ t
     for (uint32_t j = threadIdx.x; j < nfine; j += NT) e[j] = b0 + fstart[j] + chist[j];
     __syncthreads();
     // pass B: chunk-wise counting sort; fstart[f] advances as chunks are placed
+    const bool single = m <= chunk_cap;   // the bin is one chunk: pass A's histogram and scan are the chunk's
     for (uint32_t c0 = 0; c0 < m; c0 += chunk_cap) {
         const uint32_t cm = (m - c0 < chunk_cap) ? m - c0 : chunk_cap;
-        for (uint32_t j = threadIdx.x; j < nfine; j += NT) chist[j] = 0;
-        __syncthreads();
-        for (uint32_t k = threadIdx.x; k < cm; k += NT) atomicAdd(&chist[key[c0 + k] & fmask], 1u);
-        __syncthreads();
-        block_exclusive_scan<NT>(chist, cstart, nfine, tmp);
-        for (uint32_t j = threadIdx.x; j < nfine; j += NT) ccur[j] = cstart[j];
+        if (single) {
+            for (uint32_t j = threadIdx.x; j < nfine; j += NT) cstart[j] = ccur[j] = fstart[j];
+        } else {
+            for (uint32_t j = threadIdx.x; j < nfine; j += NT) chist[j] = 0;
+            __syncthreads();
+            for (uint32_t k = threadIdx.x; k < cm; k += NT) atomicAdd(&chist[key[c0 + k] & fmask], 1u);
+            __syncthreads();
+            block_exclusive_scan<NT>(chist, cstart, nfine, tmp);
+            for (uint32_t j = threadIdx.x; j < nfine; j += NT) ccur[j] = cstart[j];
+        }
         __syncthreads();
         for (uint32_t k = threadIdx.x; k < cm; k += NT) {
             const uint32_t f = key[c0 + k] & fmask;

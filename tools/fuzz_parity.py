@@ -86,6 +86,8 @@ def main():
             bases[2] = port.group_op(curve, group, 3, bases[0])
             bases[3] = port.group_consts(curve, group)[1]
         c = int(rng.choice([0, 0, 0, 2, 3, 5, 7, 9, 11, 13, 16]))
+        # amdmsm_opts.endomorphism: every base here is a multiple of the generator, so all modes must agree
+        eng.endomorphism = int(rng.choice([0, 1, 2, 2, -1]))
         form = int(rng.integers(2))
         chunks = int(rng.choice([1, 1, 2, 3, 8]))
         want = port.multi_exp(curve, group, bases, sc, port.BDLO12_SIGNED, 1, chunks=4, omp=True)
@@ -93,7 +95,8 @@ def main():
         it += 1
         if not (got == want).all():
             fails += 1
-            print(f"MISMATCH it={it} {name} n={n} pattern={pattern} c={c} form={form} chunks={chunks} first={first}", flush=True)
+            print(f"MISMATCH it={it} {name} n={n} pattern={pattern} c={c} form={form} chunks={chunks} first={first} "
+                  f"endomorphism={eng.endomorphism}", flush=True)
         if it % 50 == 0:
             print(f"[fuzz] {it} cases, {fails} mismatches", flush=True)
     print(f"[fuzz] done: {it} cases, {fails} mismatches")
