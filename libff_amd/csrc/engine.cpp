@@ -248,15 +248,14 @@ int make_plan(const group_vtable *vt, size_t n, int c_req, int L_req, plan_t &p,
     // (groups whose reduction lanes are two physical lanes wide -- fp2h.cuh, reduce_fold == 32 --
     // need twice the L for the same wave count: bls12_377 G2 2^21 3.87 -> 2.96 ms with L = 16)
     const size_t red_lanes = (size_t)(64 / vt->reduce_fold);
+    // The smallest L whose lanes the device holds at one wave per SIMD (65536, a few per cent more
+    // still pays: bls12_381 G1, 17 windows of 2^15 buckets, L = 8 / 16 -> 69632 / 34816 lanes, 1.24 /
+    // 1.53 ms), at most 64.  Window counts that are not powers of two used to land between one and
+    // two waves per SIMD: bls12_377 G1 2^22 (15 x 2^16 buckets) L = 8 -> 16: 2.08 -> 1.83 ms,
+    // bls12_377 G2 2^22 L = 16 -> 32: 5.36 -> 4.42 ms; bw6_761 G1 under the endomorphism split
+    // (12 x 2^15) L = 4 / 8 / 16: 8.1 / 5.6 / 6.8 ms.
     uint32_t L = 2u;
-    while (L < 64u && (size_t)p.W * p.B * red_lanes / (2 * L) >= (size_t)65536) L <<= 1;
-    // 24-limb prime field (bw6_761): a product is ~9x an 8-limb one and the kernel runs one wave
-    // per SIMD, so fewer, longer lanes win (measured 8.1 vs 10.7 ms at 2^21 with L = 16 vs 8)
-    // (and never more lanes than the device holds at once: 12 windows of the endomorphism split at
-    // 2^20 points, L = 4 / 8 / 16 -> 8.1 / 5.6 / 6.8 ms)
-    if (vt->fq_words >= 24) {
-        while (L < 64u && (size_t)p.W * p.B / L > (size_t)65536) L <<= 1;
-    }
+    while (L < 64u && (size_t)p.W * p.B * red_lanes / L > (size_t)70000) L <<= 1;
     if (L_req > 0) L = (uint32_t)L_req;
     while (L > p.B) L >>= 1;
     if (L == 0 || (L & (L - 1))) return AMDMSM_ERR_BAD_ARG;
