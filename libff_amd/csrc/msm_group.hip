@@ -992,7 +992,15 @@ AMDMSM_DEV void wave_group_sum(Jac<E>& p, uint32_t G);
 // closed by MID_G lanes each (up to MID_SPAN lanes: buckets of a few thousand entries, the
 // regime of a precomputed-table MSM or a short top window) or by a whole wave (a bucket holding
 // a large share of the input), so that no wave idles behind a single long serial sum.
-constexpr uint32_t INLINE_SPAN = 2;
+// (8-limb fields: 3 -- the short top window of the endomorphism split, ~2.3 S entries per bucket,
+// then stays out of the queue: reduction phase 0.66 -> 0.63 ms at 2^20, 0.61 -> 0.57 at 2^16,
+// alt_bn128 G2 1.27 -> 1.11; the longer additions of 12- and 24-limb fields make the third serial
+// addition cost more than the queue pass: bls12_377 G2 2.92 -> 3.31 ms, so 2 there)
+#ifdef AMDMSM_INLINE_SPAN
+constexpr uint32_t INLINE_SPAN = AMDMSM_INLINE_SPAN;
+#else
+constexpr uint32_t INLINE_SPAN = FQ::N <= 8 ? 3 : 2;
+#endif
 constexpr uint32_t MID_SPAN = 32;
 constexpr uint32_t MID_G = 8;
 
