@@ -90,8 +90,17 @@ def test_device_split_recombines(engine, port, name, curve, group):
     extra = [int.from_bytes(rng.bytes(fl * 8), "little") % r for _ in range(500)]
     plain, vals = _edge_scalars_plain(curve, port, lam, r, fl, extra)
     mont = port.fr_from_bigint(curve, plain)
+    # the split itself does not need k < r (the MSM entry points do: libff's scalars are field elements): r, r + 1, all ones
+    big_vals = [r, r + 1, (1 << (64 * fl)) - 1, (1 << (64 * fl)) - 2]
+    plain_big = np.array([[(v >> (64 * j)) & 0xFFFFFFFFFFFFFFFF for j in range(fl)] for v in vals + big_vals], dtype=np.uint64)
     for c in (2, 7, 13, 16, 20, 22):
         W = libff_amd.plan(curve, group, len(vals), window_bits=c, endomorphism=2)["num_windows"]
+        d = engine.endomorphism_digits(curve, group, plain_big, c, W, scalars_plain=True)
+        for i, k in enumerate(big_vals):
+            row = d[len(vals) + i]
+            k1 = sum(int(row[0, w]) << (c * w) for w in range(W))
+            k2 = sum(int(row[1, w]) << (c * w) for w in range(W))
+            assert (k1 + k2 * lam - k) % r == 0 and abs(k1) <= bound and abs(k2) <= bound, (c, i)
         for arr, is_plain in ((plain, True), (mont, False)):
             d = engine.endomorphism_digits(curve, group, arr, c, W, scalars_plain=is_plain)
             assert d.shape == (len(vals), 2, W)
@@ -193,3 +202,4 @@ def test_headline_size_same_result_with_and_without(port):
     one, _ = port.group_consts(curve, group)
     want = port.group_op(curve, group, 4, port.scalar_mul(curve, group, one, port.fr_from_bigint(curve, k_plain)[0]))
     assert (outs[0] == want).all()
+
