@@ -29,6 +29,8 @@
 #include "wide.cuh"
 
 #include <algorithm>
+#include <cstdio>
+#include <vector>
 #include <type_traits>
 
 #ifndef AMDMSM_GROUP
@@ -907,7 +909,28 @@ __global__ void __launch_bounds__(TPB, AMDMSM_ACC_WAVES) k_accumulate(const uint
                                                     uint32_t* __restrict__ buckets, uint32_t* __restrict__ part_first,
                                                     uint32_t* __restrict__ part_last, uint32_t* __restrict__ cont_bucket,
                                                     int W, uint32_t B, uint32_t S, uint32_t T,
-                                                    const uint32_t* __restrict__ endo_pts, uint32_t n_real) {
+                                                    const uint32_t* __restrict__ endo_pts, uint32_t n_real
+#ifdef AMDMSM_ACC_TRACE
+                                                    , unsigned long long* __restrict__ trace
+#endif
+                                                    ) {
+#ifdef AMDMSM_ACC_TRACE
+    // experiment: wall-clock (100 MHz) start / end of every wave, and where it ran
+    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+    struct trace_end {
+        unsigned long long* p;
+        unsigned long long t0;
+        __device__ ~trace_end() {
+            if ((threadIdx.x & 63u) == 0) {
+                const size_t wv = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+                p[3 * wv] = t0;
+                p[3 * wv + 1] = __builtin_amdgcn_s_memrealtime();
+                p[3 * wv + 2] = (unsigned long long)__builtin_amdgcn_s_getreg((15 << 11) | 4) |
+                                ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32);   // HW_ID, XCC_ID
+            }
+        }
+    } trace_guard{trace, t_start};
+#endif
     // entries >= n_real (endomorphism split only; otherwise n_real = 2^31) name phi(P_(e - n_real)),
     // record e - n_real of endo_pts (k_endo_points)
     const size_t g = gtid() / ACC_LANES;   // split form: lanes 2g, 2g+1 work on the same entries
@@ -940,7 +963,30 @@ __global__ void __launch_bounds__(TPB, AMDMSM_ACC_WAVES) k_accumulate(const uint
     // kernel's memory traffic).  The last chunk of a lane may read up to 15 entries past its
     // range: the list allocation carries that much slack (make_plan).
     __shared__ uint32_t staged[16 * TPB];   // [entry in chunk][thread]: conflict-free both ways
+    // The SIMD issues from its oldest ready wave first, so four equal waves that start together do
+    // not finish together: traced at 2^20 points (tools/acc_trace.py) the four waves of a SIMD end
+    // at 0.36 / 0.66 / 0.85 / 1.0 of the launch, and the last one runs alone -- at about 60 % of the
+    // multiplier's rate -- for the final sixth.  Priorities that fall with progress (3 for the
+    // first half of the lane's entries, 2 up to 7/8, 1 up to 15/16, then 0) let the waves that are
+    // behind catch up at those marks, so that the four end within a few per cent of each other
+    // (what is left is the spread between XCDs): 1.58 -> 1.41 ms in the traced build.
+#ifndef AMDMSM_ACC_PRIO
+#define AMDMSM_ACC_PRIO 1
+#endif
+#if AMDMSM_ACC_PRIO
+    const uint32_t span_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)S);
+    const uint32_t mark1 = span_u / 2, mark2 = span_u - span_u / 8, mark3 = span_u - span_u / 16;
+    __builtin_amdgcn_s_setprio(3);
+#endif
     for (uint32_t k = lo; k < hi; ++k) {
+#if AMDMSM_ACC_PRIO
+        {
+            const uint32_t j = (uint32_t)__builtin_amdgcn_readfirstlane((int)(k - lo));
+            if (j == mark1) __builtin_amdgcn_s_setprio(2);
+            if (j == mark2) __builtin_amdgcn_s_setprio(1);
+            if (j == mark3) __builtin_amdgcn_s_setprio(0);
+        }
+#endif
         const uint32_t kk = (k - lo) & 15u;
         if (kk == 0) {
             uint32_t v[16];
@@ -1968,9 +2014,35 @@ void l_sort(hipStream_t st, const uint32_t* scalars, size_t n, int mont, int c, 
 void l_accumulate(hipStream_t st, const uint32_t* ends, const uint32_t* lists, size_t list_stride, const uint32_t* bases,
                   uint32_t* buckets, uint32_t* part_first, uint32_t* part_last, uint32_t* cont_bucket, int W, uint32_t B,
                   uint32_t S, uint32_t T, const uint32_t* endo_pts, size_t n_real) {
+#ifdef AMDMSM_ACC_TRACE
+    {
+        const size_t waves = (size_t)blocks_for((size_t)W * T * ACC_LANES) * TPB / 64;
+        static unsigned long long* d_trace = nullptr;
+        static size_t cap = 0;
+        if (cap < waves) {
+            if (d_trace) (void)hipFree(d_trace);
+            (void)hipMalloc(&d_trace, waves * 24);
+            cap = waves;
+        }
+        (void)hipMemsetAsync(d_trace, 0, waves * 24, st);
+        hipLaunchKernelGGL(k_accumulate, dim3(blocks_for((size_t)W * T * ACC_LANES)), dim3(TPB), 0, st, ends, lists,
+                           list_stride, bases, buckets, part_first, part_last, cont_bucket, W, B, S, T, endo_pts,
+                           endo_pts ? (uint32_t)n_real : 0x80000000u, d_trace);
+        if (const char* path = getenv("AMDMSM_ACC_TRACE_FILE")) {
+            (void)hipStreamSynchronize(st);
+            std::vector<unsigned long long> h(waves * 3);
+            (void)hipMemcpy(h.data(), d_trace, waves * 24, hipMemcpyDeviceToHost);
+            if (FILE* f = fopen(path, "wb")) {
+                fwrite(h.data(), 8, h.size(), f);
+                fclose(f);
+            }
+        }
+    }
+#else
     hipLaunchKernelGGL(k_accumulate, dim3(blocks_for((size_t)W * T * ACC_LANES)), dim3(TPB), 0, st, ends, lists, list_stride,
                        bases, buckets, part_first, part_last, cont_bucket, W, B, S, T, endo_pts,
                        endo_pts ? (uint32_t)n_real : 0x80000000u);
+#endif
 }
 void l_endo_points(hipStream_t st, const uint32_t* bases, size_t n, uint32_t* out) {
     if (!n) return;
