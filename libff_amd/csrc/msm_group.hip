@@ -909,7 +909,7 @@ __global__ void __launch_bounds__(TPB, AMDMSM_ACC_WAVES) k_accumulate(const uint
                                                     uint32_t* __restrict__ buckets, uint32_t* __restrict__ part_first,
                                                     uint32_t* __restrict__ part_last, uint32_t* __restrict__ cont_bucket,
                                                     int W, uint32_t B, uint32_t S, uint32_t T,
-                                                    const uint32_t* __restrict__ endo_pts, uint32_t n_real
+                                                    const uint32_t* __restrict__ endo_pts, uint32_t n_real, int sync_waves
 #ifdef AMDMSM_ACC_TRACE
                                                     , unsigned long long* __restrict__ trace
 #endif
@@ -974,9 +974,13 @@ __global__ void __launch_bounds__(TPB, AMDMSM_ACC_WAVES) k_accumulate(const uint
 #define AMDMSM_ACC_PRIO 1
 #endif
 #if AMDMSM_ACC_PRIO
+    // (only for launches of one or two rounds of resident waves -- sync_waves: in a long launch the
+    // newcomers' high priority holds back the waves that are about to free their slots, 2^24 points:
+    // 18.0 -> 18.8 ms, 2^26: 67.3 -> 68.8)
     const uint32_t span_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)S);
-    const uint32_t mark1 = span_u / 2, mark2 = span_u - span_u / 8, mark3 = span_u - span_u / 16;
-    __builtin_amdgcn_s_setprio(3);
+    const uint32_t mark1 = sync_waves ? span_u / 2 : 0xffffffffu, mark2 = sync_waves ? span_u - span_u / 8 : 0xffffffffu,
+                   mark3 = sync_waves ? span_u - span_u / 16 : 0xffffffffu;
+    if (sync_waves) __builtin_amdgcn_s_setprio(3);
 #endif
     for (uint32_t k = lo; k < hi; ++k) {
 #if AMDMSM_ACC_PRIO
@@ -1091,9 +1095,20 @@ __global__ void __launch_bounds__(64) k_accumulate_fixup(const uint32_t* __restr
     if (span == 0 || span > INLINE_SPAN) return;
     Xyzz<E> acc, x;
     load_xyzz(acc, part_last + g * ZZW);
+#ifndef AMDMSM_FIX_PRIO
+#define AMDMSM_FIX_PRIO 1
+#endif
+    // priority falling with progress, as in k_accumulate: the waves of a SIMD end together
+    if (AMDMSM_FIX_PRIO) __builtin_amdgcn_s_setprio(3);
     for (uint32_t u = t + 1; u <= t_last; ++u) {
         load_xyzz(x, part_first + (w * T + u) * ZZW);
         xyzz_add(acc, acc, x);
+        if (AMDMSM_FIX_PRIO) {
+            const uint32_t done = (uint32_t)__builtin_amdgcn_readfirstlane((int)(u - t));
+            if (done == 1) __builtin_amdgcn_s_setprio(2);
+            if (done == 2) __builtin_amdgcn_s_setprio(1);
+            if (done >= 3) __builtin_amdgcn_s_setprio(0);
+        }
     }
     store_xyzz(buckets + (w * B + b) * ZZW, acc);
 }
@@ -2011,9 +2026,11 @@ void l_sort(hipStream_t st, const uint32_t* scalars, size_t n, int mont, int c, 
     hipLaunchKernelGGL(k_sort_big_scatter, dim3(2048), dim3(SORT_TPB), big_lds, st, tmp_payload, tmp_key16, coarse, stride, c,
                        hb, sg.big_cap, big, lists);
 }
+size_t l_accumulate_resident_lanes();
 void l_accumulate(hipStream_t st, const uint32_t* ends, const uint32_t* lists, size_t list_stride, const uint32_t* bases,
                   uint32_t* buckets, uint32_t* part_first, uint32_t* part_last, uint32_t* cont_bucket, int W, uint32_t B,
                   uint32_t S, uint32_t T, const uint32_t* endo_pts, size_t n_real) {
+    const int sync_waves = (size_t)W * T * ACC_LANES <= 2 * l_accumulate_resident_lanes() * ACC_LANES ? 1 : 0;
 #ifdef AMDMSM_ACC_TRACE
     {
         const size_t waves = (size_t)blocks_for((size_t)W * T * ACC_LANES) * TPB / 64;
@@ -2027,7 +2044,7 @@ void l_accumulate(hipStream_t st, const uint32_t* ends, const uint32_t* lists, s
         (void)hipMemsetAsync(d_trace, 0, waves * 24, st);
         hipLaunchKernelGGL(k_accumulate, dim3(blocks_for((size_t)W * T * ACC_LANES)), dim3(TPB), 0, st, ends, lists,
                            list_stride, bases, buckets, part_first, part_last, cont_bucket, W, B, S, T, endo_pts,
-                           endo_pts ? (uint32_t)n_real : 0x80000000u, d_trace);
+                           endo_pts ? (uint32_t)n_real : 0x80000000u, sync_waves, d_trace);
         if (const char* path = getenv("AMDMSM_ACC_TRACE_FILE")) {
             (void)hipStreamSynchronize(st);
             std::vector<unsigned long long> h(waves * 3);
@@ -2041,7 +2058,7 @@ void l_accumulate(hipStream_t st, const uint32_t* ends, const uint32_t* lists, s
 #else
     hipLaunchKernelGGL(k_accumulate, dim3(blocks_for((size_t)W * T * ACC_LANES)), dim3(TPB), 0, st, ends, lists, list_stride,
                        bases, buckets, part_first, part_last, cont_bucket, W, B, S, T, endo_pts,
-                       endo_pts ? (uint32_t)n_real : 0x80000000u);
+                       endo_pts ? (uint32_t)n_real : 0x80000000u, sync_waves);
 #endif
 }
 void l_endo_points(hipStream_t st, const uint32_t* bases, size_t n, uint32_t* out) {
