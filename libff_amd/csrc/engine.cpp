@@ -215,6 +215,11 @@ int choose_c(const group_vtable *vt, size_t n, bool glv = false, double *cost_ou
     double best = 1e300;
     int best_c = 2;
     for (int c = 2; c <= 22; ++c) {
+        // below 2^16 points everything is launch and chain latency, which the model does not describe:
+        // measured (2^8 .. 2^15, profiles/r02_experiments.txt) c = 8 -- 128 buckets, a window's 64
+        // segments fold inside one wave, no second reduction launch -- beats every c from 9 to 15
+        // (2^14: 0.90 vs 1.02 ms at c = 10), and c = 16 takes over at 2^15 / 2^16
+        if (n < 65536 && c > 8 && c < 16) continue;
         const double cost = plan_cost(vt, n, c, glv);
         if (cost < best) {
             best = cost;
