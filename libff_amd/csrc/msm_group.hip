@@ -228,45 +228,57 @@ using GLV = typename GP::glv;
 constexpr int GLV_HW = GLV::HW;       // limbs of |k1|, |k2|
 constexpr int GLV_HC = GLV::HW + 1;   // working width: two's complement with room for the sign
 
+// 96-bit column accumulator for the schoolbook products below: acc += a * b is one v_mad_u64_u32
+// plus the carry into the top word
+struct glv_acc {
+    uint64_t lo;
+    uint32_t hi;
+};
+AMDMSM_DEV void glv_mac(glv_acc& s, uint32_t a, uint32_t b) {
+    const uint64_t t = (uint64_t)a * b + s.lo;
+    s.hi += t < s.lo ? 1u : 0u;
+    s.lo = t;
+}
+AMDMSM_DEV void glv_add(glv_acc& s, uint32_t v) {
+    const uint64_t t = s.lo + v;
+    s.hi += t < s.lo ? 1u : 0u;
+    s.lo = t;
+}
+AMDMSM_DEV uint32_t glv_next_column(glv_acc& s) {   // emit the low word, shift down by one word
+    const uint32_t w = (uint32_t)s.lo;
+    s.lo = (s.lo >> 32) | ((uint64_t)s.hi << 32);
+    s.hi = 0;
+    return w;
+}
 // low GLV_HC limbs of (k G + 2^(s-1)) >> s, s = 32 (FRW + 1): Babai rounding of k b / r
 AMDMSM_DEV void glv_round_mul(uint32_t (&c)[GLV_HC], const uint32_t (&k)[FRW], const uint32_t (&G)[GLV::GW]) {
-    uint64_t carry = 0;
+    glv_acc s{0, 0};
 #pragma unroll
     for (int col = 0; col < FRW + 1 + GLV_HC; ++col) {
-        uint64_t lo = carry & 0xffffffffull, hi = carry >> 32;
-        if (col == FRW) lo += 0x80000000ull;
+        if (col == FRW) glv_add(s, 0x80000000u);
 #pragma unroll
         for (int i = 0; i < FRW; ++i) {
             const int j = col - i;
-            if (j >= 0 && j < GLV::GW) {
-                const uint64_t p = (uint64_t)k[i] * G[j];
-                lo += (uint32_t)p;
-                hi += p >> 32;
-            }
+            if (j >= 0 && j < GLV::GW) glv_mac(s, k[i], G[j]);
         }
-        hi += lo >> 32;
-        if (col >= FRW + 1) c[col - FRW - 1] = (uint32_t)lo;
-        carry = hi;
+        const uint32_t w = glv_next_column(s);
+        if (col >= FRW + 1) c[col - FRW - 1] = w;
     }
 }
 // t = k (if ADD_K) + c1 * A + c2 * B  mod 2^(32 GLV_HC)
 template <bool ADD_K>
 AMDMSM_DEV void glv_combine(uint32_t (&t)[GLV_HC], const uint32_t (&k)[FRW], const uint32_t (&c1)[GLV_HC],
                             const uint32_t (&A)[GLV_HC], const uint32_t (&c2)[GLV_HC], const uint32_t (&B)[GLV_HC]) {
-    uint64_t carry = 0;
+    glv_acc s{0, 0};
 #pragma unroll
     for (int col = 0; col < GLV_HC; ++col) {
-        uint64_t lo = carry & 0xffffffffull, hi = carry >> 32;
-        if (ADD_K && col < FRW) lo += k[col];
+        if (ADD_K && col < FRW) glv_add(s, k[col]);
 #pragma unroll
         for (int i = 0; i <= col; ++i) {
-            const uint64_t p = (uint64_t)c1[i] * A[col - i], q = (uint64_t)c2[i] * B[col - i];
-            lo += (uint64_t)(uint32_t)p + (uint32_t)q;
-            hi += (p >> 32) + (q >> 32);
+            glv_mac(s, c1[i], A[col - i]);
+            glv_mac(s, c2[i], B[col - i]);
         }
-        hi += lo >> 32;
-        t[col] = (uint32_t)lo;
-        carry = hi;
+        t[col] = glv_next_column(s);
     }
 }
 // two's complement t -> (|t|, sign)
