@@ -146,7 +146,9 @@ int amdmsm_batch_to_special(amdmsm_ctx *ctx, int curve, int group, void *elems_x
  * without amdmsm_invalidate_bases (any registration overlapping [host_ptr, host_ptr + bytes);
  * NULL = all) or amdmsm_unregister_bases.  AMDMSM_BASE_CACHE_MB=<MiB> in the environment makes
  * the host entry points register what they see automatically (LRU within the cap); off by default
- * because of that promise. */
+ * because of that promise.  A registered vector also keeps the (beta x, y) records of the
+ * endomorphism split (amdmsm_opts.endomorphism) once a call has used them: twice the compact
+ * affine bytes in HBM, and no per-call kernel for them. */
 int amdmsm_register_bases(amdmsm_ctx *ctx, int curve, int group, const void *bases_xyz,
                           size_t base_stride_bytes, int base_form, size_t n, uint64_t *handle);
 int amdmsm_unregister_bases(amdmsm_ctx *ctx, uint64_t handle);

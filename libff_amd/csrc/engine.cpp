@@ -57,6 +57,7 @@ struct base_entry {
     const char *host = nullptr;
     size_t n = 0, stride = 0;
     void *d_aff = nullptr;
+    void *d_endo = nullptr;   // phi(P) records of the whole vector (endomorphism split), built at first use
     bool automatic = false;   // created by AMDMSM_BASE_CACHE, evictable
     uint64_t last_use = 0;
 };
@@ -399,7 +400,7 @@ struct msm_hook {
 };
 int msm_device_impl(amdmsm_ctx *ctx, const group_vtable *vt, const uint32_t *d_bases, const uint32_t *d_scalars,
                     size_t n, uint32_t *d_out, const amdmsm_opts *opts, int table_digits = 0,
-                    const msm_hook *hook = nullptr) {
+                    const msm_hook *hook = nullptr, const uint32_t *d_endo_resident = nullptr) {
     hipStream_t st = (opts && opts->stream) ? (hipStream_t)opts->stream : ctx->stream;
     const int form = opts ? opts->out_form : AMDMSM_OUT_LIBFF;
     const int mont = (opts && opts->scalars_plain) ? 0 : 1;
@@ -436,8 +437,9 @@ int msm_device_impl(amdmsm_ctx *ctx, const group_vtable *vt, const uint32_t *d_b
     record(ctx, sl, 0, st);
     // phi(P) of every base (endomorphism split): independent of the sort, so it runs beside it on
     // the slot's side stream when the bases are already on the device (no upload hook)
-    uint32_t *endo_pts = glv ? (uint32_t *)(ws + p.off_endo) : nullptr;
-    const bool endo_beside = glv && !(hook && hook->fn);
+    // (d_endo_resident: the records already exist, kept with a registered base vector)
+    const uint32_t *endo_pts = !glv ? nullptr : (d_endo_resident ? d_endo_resident : (const uint32_t *)(ws + p.off_endo));
+    const bool endo_beside = glv && !d_endo_resident && !(hook && hook->fn);
     if (endo_beside) HIP_TRY(ctx, hipEventRecord(sl.tail_done[0], st));
     if ((atomic_sort || p.c > 22) && !table_digits) {
         HIP_TRY(ctx, hipMemsetAsync(counts, 0, (size_t)p.W * p.B * 4, st));
@@ -457,7 +459,7 @@ int msm_device_impl(amdmsm_ctx *ctx, const group_vtable *vt, const uint32_t *d_b
     // second half only 0.35, after it 0.30; the plain path's sort takes 0.24)
     if (endo_beside) {   // enqueued after the sort kernels, ordered only behind the start of the call
         HIP_TRY(ctx, hipStreamWaitEvent(sl.side[0], sl.tail_done[0], 0));
-        vt->endo_points(sl.side[0], d_bases, n, endo_pts);
+        vt->endo_points(sl.side[0], d_bases, n, (uint32_t *)(ws + p.off_endo));
         HIP_TRY(ctx, hipEventRecord(sl.acc_done[0], sl.side[0]));
     }
     HIP_TRY(ctx, hipMemsetAsync(buckets, 0, (size_t)p.W * p.B * vt->el_words * 16, st));
@@ -469,7 +471,7 @@ int msm_device_impl(amdmsm_ctx *ctx, const group_vtable *vt, const uint32_t *d_b
         if (wait_for) HIP_TRY(ctx, hipStreamWaitEvent(st, wait_for, 0));
     }
     if (endo_beside) HIP_TRY(ctx, hipStreamWaitEvent(st, sl.acc_done[0], 0));
-    else if (glv) vt->endo_points(st, d_bases, n, endo_pts);
+    else if (glv && !d_endo_resident) vt->endo_points(st, d_bases, n, (uint32_t *)(ws + p.off_endo));
     const size_t zzw = (size_t)vt->el_words * 4, xyzw = (size_t)vt->el_words * 3;   // words per XYZZ / Jacobian point
     const size_t M0 = p.B / p.L, cap1 = M0 / 2 + 1;
     uint32_t *pfirst = (uint32_t *)(ws + p.off_pfirst), *plast = (uint32_t *)(ws + p.off_plast);
@@ -634,6 +636,7 @@ void amdmsm_ctx_destroy(amdmsm_ctx *ctx) {
         }
         for (auto &be : ctx->bases) {
             if (be.d_aff) (void)hipFree(be.d_aff);
+            if (be.d_endo) (void)hipFree(be.d_endo);
         }
         if (ctx->bases_ready) (void)hipEventDestroy(ctx->bases_ready);
         if (ctx->host_done) (void)hipEventDestroy(ctx->host_done);
@@ -994,7 +997,8 @@ int ensure_buf(amdmsm_ctx *ctx, grow_buf &b, size_t bytes) {
 }
 
 // resident compact-affine copy of the host range [bases, bases + n*stride), or null
-void *find_resident_bases(amdmsm_ctx *ctx, const group_vtable *vt, const void *bases, size_t stride, int form, size_t n) {
+void *find_resident_bases(amdmsm_ctx *ctx, const group_vtable *vt, const void *bases, size_t stride, int form, size_t n,
+                          base_entry **entry = nullptr, size_t *first = nullptr) {
     const char *lo = (const char *)bases;
     for (auto &e : ctx->bases) {
         if (e.curve != vt->curve || e.group != vt->group || e.form != form || e.stride != stride) continue;
@@ -1002,6 +1006,8 @@ void *find_resident_bases(amdmsm_ctx *ctx, const group_vtable *vt, const void *b
         const size_t off = (size_t)(lo - e.host);
         if (off % stride) continue;
         e.last_use = ++ctx->use_clock;
+        if (entry) *entry = &e;
+        if (first) *first = off / stride;
         return (char *)e.d_aff + (off / stride) * (size_t)vt->el_words * 8;
     }
     return nullptr;
@@ -1052,6 +1058,7 @@ size_t auto_cache_cap_bytes() {
 
 void drop_entry(amdmsm_ctx *ctx, size_t i) {
     if (ctx->bases[i].d_aff) (void)hipFree(ctx->bases[i].d_aff);
+    if (ctx->bases[i].d_endo) (void)hipFree(ctx->bases[i].d_endo);
     ctx->bases.erase(ctx->bases.begin() + (long)i);
 }
 
@@ -1114,13 +1121,34 @@ int host_msm_enqueue(amdmsm_ctx *ctx, const group_vtable *vt, const void *bases_
     else o.out_form = AMDMSM_OUT_LIBFF;
     o.stream = st;
     void *d_aff = nullptr;
+    const uint32_t *d_endo = nullptr;
     bases_upload up{ctx, vt, bases_xyz, stride, n, base_form};
     msm_hook hook;
     if (n) {
         rc = ensure_buf(ctx, ctx->hb_sc, n * fr_bytes);
         if (rc) return rc;
-        d_aff = find_resident_bases(ctx, vt, bases_xyz, stride, base_form, n);
-        if (!d_aff) d_aff = auto_cache_bases(ctx, vt, bases_xyz, stride, base_form, n);
+        base_entry *be = nullptr;
+        size_t first = 0;
+        d_aff = find_resident_bases(ctx, vt, bases_xyz, stride, base_form, n, &be, &first);
+        if (!d_aff && auto_cache_bases(ctx, vt, bases_xyz, stride, base_form, n))
+            d_aff = find_resident_bases(ctx, vt, bases_xyz, stride, base_form, n, &be, &first);
+        if (d_aff && be && use_endomorphism(vt, n, &o, 0)) {
+            // resident bases keep their phi(P) records too: built once (whole vector), then every
+            // split MSM over them skips k_endo_points
+            if (!be->d_endo) {
+                if (hipMalloc(&be->d_endo, std::max<size_t>(be->n * aff_bytes, 256)) == hipSuccess) {
+                    vt->endo_points(st, (const uint32_t *)be->d_aff, be->n, (uint32_t *)be->d_endo);
+                    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+                        (void)hipFree(be->d_endo);
+                        be->d_endo = nullptr;
+                    }
+                } else {
+                    be->d_endo = nullptr;   // no room: the per-call kernel does it
+                    (void)hipGetLastError();
+                }
+            }
+            if (be->d_endo) d_endo = (const uint32_t *)((const char *)be->d_endo + first * aff_bytes);
+        }
         if (!d_aff) {
             rc = ensure_buf(ctx, ctx->hb_src, n * stride);
             if (rc == AMDMSM_OK) rc = ensure_buf(ctx, ctx->hb_aff, n * aff_bytes);
@@ -1136,7 +1164,7 @@ int host_msm_enqueue(amdmsm_ctx *ctx, const group_vtable *vt, const void *bases_
         }
     }
     return msm_device_impl(ctx, vt, (const uint32_t *)d_aff, (const uint32_t *)ctx->hb_sc.p, n, (uint32_t *)ctx->hb_out.p, &o,
-                           0, &hook);
+                           0, &hook, d_endo);
 }
 
 // one partial point from the device that produced it to the combining device (xGMI peer copy)
