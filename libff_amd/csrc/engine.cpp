@@ -440,7 +440,9 @@ int msm_device_impl(amdmsm_ctx *ctx, const group_vtable *vt, const uint32_t *d_b
     // (d_endo_resident: the records already exist, kept with a registered base vector)
     const uint32_t *endo_pts = !glv ? nullptr : (d_endo_resident ? d_endo_resident : (const uint32_t *)(ws + p.off_endo));
     const bool endo_beside = glv && !d_endo_resident && !(hook && hook->fn);
-    if (endo_beside) HIP_TRY(ctx, hipEventRecord(sl.tail_done[0], st));
+    // the side stream also clears the bucket array and the queue heads while the sort runs (both
+    // are first touched by the accumulation)
+    HIP_TRY(ctx, hipEventRecord(sl.tail_done[0], st));
     if ((atomic_sort || p.c > 22) && !table_digits) {
         HIP_TRY(ctx, hipMemsetAsync(counts, 0, (size_t)p.W * p.B * 4, st));
         vt->count(st, d_scalars, n, mont, p.c, p.W, counts);
@@ -457,21 +459,20 @@ int msm_device_impl(amdmsm_ctx *ctx, const group_vtable *vt, const uint32_t *d_b
     }
     // (measured at 2^20 points: beside the whole sort 0.29 ms for the phase, beside its LDS-bound
     // second half only 0.35, after it 0.30; the plain path's sort takes 0.24)
-    if (endo_beside) {   // enqueued after the sort kernels, ordered only behind the start of the call
-        HIP_TRY(ctx, hipStreamWaitEvent(sl.side[0], sl.tail_done[0], 0));
-        vt->endo_points(sl.side[0], d_bases, n, (uint32_t *)(ws + p.off_endo));
-        HIP_TRY(ctx, hipEventRecord(sl.acc_done[0], sl.side[0]));
-    }
-    HIP_TRY(ctx, hipMemsetAsync(buckets, 0, (size_t)p.W * p.B * vt->el_words * 16, st));
-    for (int g = 0; g < p.G; ++g) HIP_TRY(ctx, hipMemsetAsync(ws + p.off_queue + g * p.queue_stride, 0, 8, st));
+    // enqueued after the sort kernels, ordered only behind the start of the call
+    HIP_TRY(ctx, hipStreamWaitEvent(sl.side[0], sl.tail_done[0], 0));
+    HIP_TRY(ctx, hipMemsetAsync(buckets, 0, (size_t)p.W * p.B * vt->el_words * 16, sl.side[0]));
+    for (int g = 0; g < p.G; ++g) HIP_TRY(ctx, hipMemsetAsync(ws + p.off_queue + g * p.queue_stride, 0, 8, sl.side[0]));
+    if (endo_beside) vt->endo_points(sl.side[0], d_bases, n, (uint32_t *)(ws + p.off_endo));
+    HIP_TRY(ctx, hipEventRecord(sl.acc_done[0], sl.side[0]));
     if (hook && hook->fn) {
         hipEvent_t wait_for = nullptr;
         rc = hook->fn(hook->arg, &wait_for);
         if (rc) return rc;
         if (wait_for) HIP_TRY(ctx, hipStreamWaitEvent(st, wait_for, 0));
     }
-    if (endo_beside) HIP_TRY(ctx, hipStreamWaitEvent(st, sl.acc_done[0], 0));
-    else if (glv && !d_endo_resident) vt->endo_points(st, d_bases, n, (uint32_t *)(ws + p.off_endo));
+    HIP_TRY(ctx, hipStreamWaitEvent(st, sl.acc_done[0], 0));
+    if (glv && !d_endo_resident && !endo_beside) vt->endo_points(st, d_bases, n, (uint32_t *)(ws + p.off_endo));
     const size_t zzw = (size_t)vt->el_words * 4, xyzw = (size_t)vt->el_words * 3;   // words per XYZZ / Jacobian point
     const size_t M0 = p.B / p.L, cap1 = M0 / 2 + 1;
     uint32_t *pfirst = (uint32_t *)(ws + p.off_pfirst), *plast = (uint32_t *)(ws + p.off_plast);
