@@ -49,7 +49,7 @@ for _g in ("bls12_377_g1", "bls12_381_g1"):
 ARCH = "gfx950"
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-I" + INCLUDE, "-I" + CSRC,
           "-Wno-unused-result"]
-DEVICE_DEPS = ["msm_group.hip", "fp.cuh", "fp2.cuh", "fp2h.cuh", "ec.cuh", "wide.cuh", "mac_chain.inc", "curve_params.h", "group_vtable.h", os.path.join(HERE, "build.py")]
+DEVICE_DEPS = ["msm_group.hip", "fp.cuh", "fp2.cuh", "fp2h.cuh", "ec.cuh", "wide.cuh", "wide28.cuh", "mac_chain.inc", "curve_params.h", "group_vtable.h", os.path.join(HERE, "build.py")]
 HOST_DEPS = ["engine.cpp", "ffi.cpp", "engine_internal.h", "group_vtable.h", os.path.join(INCLUDE, "amdmsm.h"),
              os.path.join(INCLUDE, "libff_amd_ffi.h")]
 

@@ -10,6 +10,7 @@
 #include "ec.cuh"
 #include "fp2.cuh"
 #include "wide.cuh"
+#include "wide28.cuh"
 
 using namespace amdmsm;
 
@@ -179,6 +180,91 @@ int run(const char* name) {
     return total;
 }
 
+// Runs of c doublings: wide28.cuh (28-bit limbs, lazy linear operations, canonical in / out) against c
+// calls of jac_dbl_wide, word for word.  in: per test one point (X, Y, Z) of N words each.
+template <class P>
+__global__ void __launch_bounds__(64) k_test_run28(const uint32_t* in, uint32_t* out_run, uint32_t* out_ref, int tests) {
+    constexpr int N = P::N;
+    const WideEnv<P> e = wide_env<P>();
+    for (int t = 0; t < tests; ++t) {
+        const uint32_t* b = in + (size_t)t * 3 * N;
+        const uint32_t x = e.valid ? b[e.j] : 0u, y = e.valid ? b[N + e.j] : 0u, z = e.valid ? b[2 * N + e.j] : 0u;
+        const int c = 1 + t % 22;
+        uint32_t X = x, Y = y, Z = z;
+        jac_dbl_run28<P>(e, X, Y, Z, c);
+        uint32_t X2 = x, Y2 = y, Z2 = z;
+        for (int i = 0; i < c; ++i) jac_dbl_wide<P>(e, X2, Y2, Z2);
+        if (threadIdx.x < (unsigned)N) {
+            uint32_t* o = out_run + (size_t)t * 3 * N;
+            uint32_t* r = out_ref + (size_t)t * 3 * N;
+            o[e.j] = X;
+            o[N + e.j] = Y;
+            o[2 * N + e.j] = Z;
+            r[e.j] = X2;
+            r[N + e.j] = Y2;
+            r[2 * N + e.j] = Z2;
+        }
+    }
+}
+
+template <class P>
+int run28(const char* name) {
+    constexpr int N = P::N;
+    const int tests = 3000;
+    std::vector<uint32_t> in((size_t)tests * 3 * N);
+    uint64_t s = 0xd1b54a32d192ed03ull;
+    auto rnd = [&]() {
+        s ^= s << 13;
+        s ^= s >> 7;
+        s ^= s << 17;
+        return (uint32_t)(s >> 16);
+    };
+    for (size_t el = 0; el < in.size() / N; ++el) {
+        const int kind = (int)(rnd() % 8);
+        for (int i = 0; i < N; ++i) {
+            uint32_t w = rnd();
+            if (kind == 0) w = 0xffffffffu;          // long carry chains
+            if (kind == 1) w = 0;                     // zero coordinate (Z = 0: infinity)
+            if (kind == 2) w = P::P[i];               // p - small
+            in[el * N + i] = w;
+        }
+        if (kind == 2) in[el * N] -= 1 + rnd() % 3;
+        if (kind != 2) in[el * N + N - 1] %= P::P[N - 1];
+    }
+    uint32_t *d_in, *d_w, *d_r;
+    const size_t ob = in.size() * 4;
+    hipMalloc(&d_in, ob);
+    hipMalloc(&d_w, ob);
+    hipMalloc(&d_r, ob);
+    hipMemset(d_w, 0, ob);
+    hipMemset(d_r, 0xff, ob);
+    hipMemcpy(d_in, in.data(), ob, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k_test_run28<P>, dim3(1), dim3(64), 0, 0, d_in, d_w, d_r, tests);
+    std::vector<uint32_t> w(in.size()), r(in.size());
+    hipMemcpy(w.data(), d_w, ob, hipMemcpyDeviceToHost);
+    hipMemcpy(r.data(), d_r, ob, hipMemcpyDeviceToHost);
+    int bad = 0;
+    for (int t = 0; t < tests; ++t) {
+        const size_t o = (size_t)t * 3 * N;
+        bool zinf = true;
+        for (int i = 0; i < N; ++i) zinf = zinf && r[o + 2 * N + i] == 0;
+        bool same = true;
+        for (int i = 0; i < 3 * N; ++i) {
+            if (zinf && i < 2 * N) continue;   // at infinity X, Y are free
+            same = same && w[o + i] == r[o + i];
+        }
+        if (!same && bad++ == 0) {
+            printf("%s run28 first mismatch test %d (c = %d)\n  run28:", name, t, 1 + t % 22);
+            for (int i = 3 * N - 1; i >= 0; --i) printf(" %08x", w[o + i]);
+            printf("\n  ref:  ");
+            for (int i = 3 * N - 1; i >= 0; --i) printf(" %08x", r[o + i]);
+            printf("\n");
+        }
+    }
+    printf("%s: %d runs of 1..22 doublings, wide28 vs jac_dbl_wide: %s\n", name, tests, bad ? "FAIL" : "ok");
+    return bad;
+}
+
 // Fq2: per test two points (X, Y, Z) of 2N words each; out: mul, sqr of (X1, Y1) and the doubling /
 // addition results
 template <class P, int NR>
@@ -316,6 +402,7 @@ int run2(const char* name) {
 int main() {
     int bad = run<alt_bn128_fq>("alt_bn128_fq") + run<bls12_377_fq>("bls12_377_fq") + run<bw6_761_fq>("bw6_761_fq");
     bad += run2<alt_bn128_fq, -1>("alt_bn128_fq2") + run2<bls12_377_fq, -5>("bls12_377_fq2");
+    bad += run28<alt_bn128_fq>("alt_bn128_fq") + run28<bls12_377_fq>("bls12_377_fq") + run28<bls12_381_fq>("bls12_381_fq");
     printf(bad ? "WIDE TEST FAILED\n" : "WIDE TEST PASSED\n");
     return bad ? 1 : 0;
 }
