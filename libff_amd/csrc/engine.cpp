@@ -315,16 +315,19 @@ int make_plan(const group_vtable *vt, size_t n, int c_req, int L_req, plan_t &p,
     p.off_partial = off;
     off = align_up(off + (size_t)MAX_GROUPS * xyz_bytes, 256);
     // two-level sort scratch
+    // (the coarse counters and the header of the big-bin scratch are cleared by ONE memset: the
+    // scratch follows the counters directly)
     p.off_coarse = off;
     off = align_up(off + (size_t)p.W * 1025 * 4, 256);
+    p.off_big = off;
+    if (p.c <= 22) off = align_up(off + sort_geometry(n, p.c, p.W).big_words * 4, 256);
+    else off += 256;
     p.off_cursor = off;
     off = align_up(off + (size_t)p.W * 1024 * 4, 256);
     p.off_tmp_payload = off;
     off = align_up(off + (size_t)p.W * p.list_stride * 4, 256);
     p.off_tmp_key = off;
     off = align_up(off + (size_t)p.W * p.list_stride * 4, 256);   // 16-bit fine keys use half of it
-    p.off_big = off;
-    if (p.c <= 22) off = align_up(off + sort_geometry(n, p.c, p.W).big_words * 4, 256);
     p.off_endo = off;
     if (glv) off = align_up(off + (n / 2) * (size_t)vt->el_words * 2 * 4, 256);
     p.total = off;
@@ -449,8 +452,7 @@ int msm_device_impl(amdmsm_ctx *ctx, const group_vtable *vt, const uint32_t *d_b
         record(ctx, sl, 1, st);
         vt->scatter(st, d_scalars, n, mont, p.c, p.W, counts, lists, p.list_stride);
     } else {
-        HIP_TRY(ctx, hipMemsetAsync(ws + p.off_coarse, 0, (size_t)p.W * 1025 * 4, st));
-        HIP_TRY(ctx, hipMemsetAsync(ws + p.off_big, 0, 16, st));
+        HIP_TRY(ctx, hipMemsetAsync(ws + p.off_coarse, 0, p.off_big + 16 - p.off_coarse, st));   // counters + big-bin header
         record(ctx, sl, 1, st);
         vt->sort(st, d_scalars, n, mont, p.c, table_digits ? table_digits : p.W, (uint32_t *)(ws + p.off_coarse),
                  (uint32_t *)(ws + p.off_cursor), (int32_t *)lists, (uint32_t *)(ws + p.off_tmp_payload),
