@@ -1400,7 +1400,9 @@ AMDMSM_DEV typename std::enable_if<(P::N < 16), void>::type horner_chain(Jac<Fp2
     }
     for (; w >= 0; --w) {
         if (!wide_is_zero(Z)) {
-            for (int i = 0; i < c; ++i) jac_dbl_seq<F, P>(env, X, Y, Z);
+            // runs of doublings on 28-bit limbs with lazy linear operations (wide28.cuh)
+            if (c >= 4) jac_dbl_run28q<P, NR>(env, X, Y, Z, c);
+            else for (int i = 0; i < c; ++i) jac_dbl_seq<F, P>(env, X, Y, Z);
         }
         load(window_sums + (size_t)w * XYZW, X2, Y2, Z2);
         jac_add_seq<F, P>(env, X, Y, Z, X2, Y2, Z2);

@@ -399,10 +399,99 @@ int run2(const char* name) {
     return total;
 }
 
+// The same for Fq2 (WideFq2 layout): jac_dbl_run28q against c calls of jac_dbl_seq<WideFq2>.
+// in: per test one point (X, Y, Z) of 2N words each.
+template <class P, int NR>
+__global__ void __launch_bounds__(64) k_test_run28q(const uint32_t* in, uint32_t* out_run, uint32_t* out_ref, int tests) {
+    constexpr int N = P::N, EW2 = 2 * N;
+    using F = WideFq2<P, NR>;
+    const WideEnv<P> e = wide_env<P>();
+    const uint32_t row = (threadIdx.x & 63u) >> 4;
+    const uint32_t wi = F::word_index(e);
+    for (int t = 0; t < tests; ++t) {
+        const uint32_t* b = in + (size_t)t * 3 * EW2;
+        const uint32_t x = e.valid ? b[wi] : 0u, y = e.valid ? b[EW2 + wi] : 0u, z = e.valid ? b[2 * EW2 + wi] : 0u;
+        const int c = 1 + t % 22;
+        uint32_t X = x, Y = y, Z = z;
+        jac_dbl_run28q<P, NR>(e, X, Y, Z, c);
+        uint32_t X2 = x, Y2 = y, Z2 = z;
+        for (int i = 0; i < c; ++i) jac_dbl_seq<F, P>(e, X2, Y2, Z2);
+        if (row < 2 && e.valid) {
+            uint32_t* o = out_run + (size_t)t * 3 * EW2;
+            uint32_t* r = out_ref + (size_t)t * 3 * EW2;
+            o[wi] = X;
+            o[EW2 + wi] = Y;
+            o[2 * EW2 + wi] = Z;
+            r[wi] = X2;
+            r[EW2 + wi] = Y2;
+            r[2 * EW2 + wi] = Z2;
+        }
+    }
+}
+
+template <class P, int NR>
+int run28q(const char* name) {
+    constexpr int N = P::N, EW2 = 2 * N;
+    const int tests = 2000;
+    std::vector<uint32_t> in((size_t)tests * 3 * EW2);
+    uint64_t s = 0x94d049bb133111ebull;
+    auto rnd = [&]() {
+        s ^= s << 13;
+        s ^= s >> 7;
+        s ^= s << 17;
+        return (uint32_t)(s >> 16);
+    };
+    for (size_t el = 0; el < in.size() / N; ++el) {
+        const int kind = (int)(rnd() % 8);
+        for (int i = 0; i < N; ++i) {
+            uint32_t w = rnd();
+            if (kind == 0) w = 0xffffffffu;
+            if (kind == 1) w = 0;
+            if (kind == 2) w = P::P[i];
+            in[el * N + i] = w;
+        }
+        if (kind == 2) in[el * N] -= 1 + rnd() % 3;
+        if (kind != 2) in[el * N + N - 1] %= P::P[N - 1];
+    }
+    uint32_t *d_in, *d_w, *d_r;
+    const size_t ob = in.size() * 4;
+    hipMalloc(&d_in, ob);
+    hipMalloc(&d_w, ob);
+    hipMalloc(&d_r, ob);
+    hipMemset(d_w, 0, ob);
+    hipMemset(d_r, 0xff, ob);
+    hipMemcpy(d_in, in.data(), ob, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL((k_test_run28q<P, NR>), dim3(1), dim3(64), 0, 0, d_in, d_w, d_r, tests);
+    std::vector<uint32_t> w(in.size()), r(in.size());
+    hipMemcpy(w.data(), d_w, ob, hipMemcpyDeviceToHost);
+    hipMemcpy(r.data(), d_r, ob, hipMemcpyDeviceToHost);
+    int bad = 0;
+    for (int t = 0; t < tests; ++t) {
+        const size_t o = (size_t)t * 3 * EW2;
+        bool zinf = true;
+        for (int i = 0; i < EW2; ++i) zinf = zinf && r[o + 2 * EW2 + i] == 0;
+        bool same = true;
+        for (int i = 0; i < 3 * EW2; ++i) {
+            if (zinf && i < 2 * EW2) continue;
+            same = same && w[o + i] == r[o + i];
+        }
+        if (!same && bad++ == 0) {
+            printf("%s run28q first mismatch test %d (c = %d)\n  run28:", name, t, 1 + t % 22);
+            for (int i = 3 * EW2 - 1; i >= 0; --i) printf(" %08x", w[o + i]);
+            printf("\n  ref:  ");
+            for (int i = 3 * EW2 - 1; i >= 0; --i) printf(" %08x", r[o + i]);
+            printf("\n");
+        }
+    }
+    printf("%s: %d runs of 1..22 doublings, wide28 vs jac_dbl_seq<WideFq2>: %s\n", name, tests, bad ? "FAIL" : "ok");
+    return bad;
+}
+
 int main() {
     int bad = run<alt_bn128_fq>("alt_bn128_fq") + run<bls12_377_fq>("bls12_377_fq") + run<bw6_761_fq>("bw6_761_fq");
     bad += run2<alt_bn128_fq, -1>("alt_bn128_fq2") + run2<bls12_377_fq, -5>("bls12_377_fq2");
     bad += run28<alt_bn128_fq>("alt_bn128_fq") + run28<bls12_377_fq>("bls12_377_fq") + run28<bls12_381_fq>("bls12_381_fq");
+    bad += run28q<alt_bn128_fq, -1>("alt_bn128_fq2") + run28q<bls12_377_fq, -5>("bls12_377_fq2") + run28q<bls12_381_fq, -1>("bls12_381_fq2");
     printf(bad ? "WIDE TEST FAILED\n" : "WIDE TEST PASSED\n");
     return bad ? 1 : 0;
 }
