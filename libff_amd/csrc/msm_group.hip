@@ -1367,7 +1367,8 @@ AMDMSM_DEV typename std::enable_if<(P::N >= 16 && P::N < 32), void>::type horner
     }
     for (; w >= 0; --w) {
         if (!wide_is_zero(Z)) {
-            for (int i = 0; i < c; ++i) jac_dbl_wide2<P>(env, X, Y, Z);   // two products per round
+            if (c >= 4) jac_dbl_run28<P>(env, X, Y, Z, c);   // 28 limbs of 28 bits, lazy linear operations
+            else for (int i = 0; i < c; ++i) jac_dbl_wide2<P>(env, X, Y, Z);   // two products per round
         }
         load(window_sums + (size_t)w * XYZW, X2, Y2, Z2);
         jac_add_seq<F, P>(env, X, Y, Z, X2, Y2, Z2);

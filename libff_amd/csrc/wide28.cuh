@@ -4,7 +4,7 @@
 // wide.cuh keeps one canonical 32-bit limb per lane: every addition resolves a carry chain with
 // ballots and ends in a conditional subtraction, and those linear operations are almost half of a
 // doubling.  Here an element is L = ceil((bits + 10) / 28) limbs of 28 bits in lanes 0..L-1 of a
-// 16-lane row, Montgomery radix 2^(28 L), limbs kept "loose":
+// 16-lane row (32-lane row for the 24-word field of bw6_761), Montgomery radix 2^(28 L), limbs kept "loose":
 //   * a + b is one v_add per lane (limbs stay below 2^30),
 //   * a - b adds a multiple of p whose limbs (all but the top one) were lifted by 2^30 first --
 //     16 p for subtrahends below 8 p, 32 p for subtrahends below 18 p; the top limb is not lifted, so the
@@ -70,7 +70,7 @@ constexpr uint32_t cb_limb28(const cbig<NW>& a, int j, bool top) {
 }
 
 struct tab28 {
-    uint32_t v[16];
+    uint32_t v[32];
 };
 
 // HEAD: bits of headroom of the radix above the modulus (10 for the Fq runs below; 20 for the Fq2 runs,
@@ -80,7 +80,7 @@ struct W28 {
     static constexpr int N = P::N;
     static constexpr int L = (P::BITS + HEAD + 27) / 28;
     static constexpr int J = (P::BITS - 1) / 28;   // limb that holds the top bit of p
-    static_assert(L <= 16 && N < 16, "one element per 16-lane row");
+    static_assert(L <= WideEnv<P>::ROW && N < 32, "one element per 16- or 32-lane row");
     static constexpr int NW = N + 2;
     static constexpr cbig<NW> modulus() {
         cbig<NW> p{};
@@ -145,7 +145,7 @@ struct Env28 {
 AMDMSM_DEV uint32_t tab28_sel(const tab28& t, uint32_t j) {
     uint32_t r = 0;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) r = (j == (uint32_t)i) ? t.v[i] : r;
+    for (int i = 0; i < 32; ++i) r = (j == (uint32_t)i) ? t.v[i] : r;
     return r;
 }
 template <class P, int HEAD = 10>
@@ -216,10 +216,11 @@ AMDMSM_DEV void jac_dbl_28(const Env28<P, 10>& v, uint32_t& X, uint32_t& Y, uint
 // canonical words of rows 0 / 1 / 2 (value < p, Montgomery radix 2^(32 N)) -> loose 28-bit limbs, radix 2^(28 L)
 template <class P, int HEAD>
 AMDMSM_DEV uint32_t to28(const Env28<P, HEAD>& v, uint32_t w) {
-    const uint32_t rowbase = threadIdx.x & 48u;
+    constexpr uint32_t RM = (uint32_t)WideEnv<P>::ROW - 1u;
+    const uint32_t rowbase = threadIdx.x & 63u & ~RM;
     const uint32_t bit = 28u * v.j, q = bit >> 5, o = bit & 31u;
-    const uint32_t lo = (uint32_t)__shfl((int)w, (int)(rowbase + (q & 15u)), 64);
-    const uint32_t hi = (uint32_t)__shfl((int)w, (int)(rowbase + ((q + 1) & 15u)), 64);
+    const uint32_t lo = (uint32_t)__shfl((int)w, (int)(rowbase + (q & RM)), 64);
+    const uint32_t hi = (uint32_t)__shfl((int)w, (int)(rowbase + ((q + 1) & RM)), 64);
     const uint64_t both = ((uint64_t)hi << 32) | lo;
     const uint32_t limb = v.j < (uint32_t)W28<P, HEAD>::L ? (uint32_t)(both >> o) & MASK28 : 0u;
     return mul28(v, limb, v.cin);
@@ -233,27 +234,58 @@ AMDMSM_DEV uint32_t from28(const Env28<P, HEAD>& v, uint32_t a) {
     const unsigned long long cin = carry_in_mask((s >> 28) != 0u, s == MASK28);
     const uint32_t n = (s + (__builtin_amdgcn_inverse_ballot_w64(cin) ? 1u : 0u)) & MASK28;
     // regroup: word k = bits [32 k, 32 k + 32); 32 k mod 28 is a multiple of 4 below 28, two limbs suffice
-    const uint32_t rowbase = threadIdx.x & 48u;
+    constexpr uint32_t RM = (uint32_t)WideEnv<P>::ROW - 1u;
+    const uint32_t rowbase = threadIdx.x & 63u & ~RM;
     const uint32_t bit = 32u * v.j, q = bit / 28u, o = bit % 28u;
-    const uint32_t l0 = (uint32_t)__shfl((int)n, (int)(rowbase + (q & 15u)), 64);
-    const uint32_t l1 = (uint32_t)__shfl((int)n, (int)(rowbase + ((q + 1) & 15u)), 64);
+    const uint32_t l0 = (uint32_t)__shfl((int)n, (int)(rowbase + (q & RM)), 64);
+    const uint32_t l1 = (uint32_t)__shfl((int)n, (int)(rowbase + ((q + 1) & RM)), 64);
     const uint32_t word = v.e.valid ? (l0 >> o) | (uint32_t)((uint64_t)l1 << (28u - o)) : 0u;
     return wide_cond_sub_p<P>(v.e, word);
+}
+
+// the same doubling for fields of 16..31 words (two 32-lane rows): the seven products in four rounds of two,
+// as jac_dbl_wide2
+template <class P>
+AMDMSM_DEV void jac_dbl_28_two(const Env28<P, 10>& v, uint32_t& X, uint32_t& Y, uint32_t& Z) {
+    const bool r1 = (threadIdx.x & 32u) != 0;
+    uint32_t r = mul28(v, r1 ? Y : X, r1 ? Y : X);                 // XX | B
+    const uint32_t XX = row_copy<P>(v.e, r, 0), B = row_copy<P>(v.e, r, 1);
+    const uint32_t B2 = B + B, E3 = XX + XX + XX;
+    r = mul28(v, r1 ? B2 : Y, r1 ? B2 : Z);                        // Y Z | 4C
+    const uint32_t YZ = row_copy<P>(v.e, r, 0), C4 = row_copy<P>(v.e, r, 1);
+    r = mul28(v, r1 ? E3 : X, r1 ? E3 : B2);                       // 2 X B | F
+    const uint32_t XB2 = row_copy<P>(v.e, r, 0), F = row_copy<P>(v.e, r, 1);
+    const uint32_t D = XB2 + XB2;
+    X = sub28_16(v, F, D + D);
+    const uint32_t t = mul28(v, E3, sub28_32(v, D, X));
+    Y = sub28_16(v, t, C4 + C4);
+    Z = YZ + YZ;
 }
 
 // (X, Y, Z) <- 2^c (X, Y, Z): quads replicated in every row, canonical in and out
 template <class P>
 AMDMSM_DEV void jac_dbl_run28(const WideEnv<P>& e, uint32_t& X, uint32_t& Y, uint32_t& Z, int c) {
     const Env28<P, 10> v = env28<P, 10>(e);
-    const uint32_t row = (threadIdx.x & 63u) >> 4;
-    uint32_t r = to28(v, row == 0 ? X : (row == 1 ? Y : Z));
-    uint32_t X28 = from_row(r, 0), Y28 = from_row(r, 1), Z28 = from_row(r, 2);
-    for (int i = 0; i < c; ++i) jac_dbl_28<P>(v, X28, Y28, Z28);
-    // Z28 < 4 p has limbs up to 2^29 + 2^6: bring it into product range like the others
-    r = from28(v, row == 0 ? X28 : (row == 1 ? Y28 : carry28(v, Z28)));
-    X = from_row(r, 0);
-    Y = from_row(r, 1);
-    Z = from_row(r, 2);
+    if constexpr (WideEnv<P>::ROW == 16) {
+        const uint32_t row = (threadIdx.x & 63u) >> 4;
+        uint32_t r = to28(v, row == 0 ? X : (row == 1 ? Y : Z));
+        uint32_t X28 = from_row(r, 0), Y28 = from_row(r, 1), Z28 = from_row(r, 2);
+        for (int i = 0; i < c; ++i) jac_dbl_28<P>(v, X28, Y28, Z28);
+        // Z28 < 4 p has limbs up to 2^29 + 2^6: bring it into product range like the others
+        r = from28(v, row == 0 ? X28 : (row == 1 ? Y28 : carry28(v, Z28)));
+        X = from_row(r, 0);
+        Y = from_row(r, 1);
+        Z = from_row(r, 2);
+    } else {
+        const bool r1 = (threadIdx.x & 32u) != 0;
+        uint32_t r = to28(v, r1 ? Y : X);
+        uint32_t X28 = row_copy<P>(e, r, 0), Y28 = row_copy<P>(e, r, 1), Z28 = to28(v, Z);
+        for (int i = 0; i < c; ++i) jac_dbl_28_two<P>(v, X28, Y28, Z28);
+        r = from28(v, r1 ? Y28 : X28);
+        X = row_copy<P>(e, r, 0);
+        Y = row_copy<P>(e, r, 1);
+        Z = from28(v, carry28(v, Z28));
+    }
 }
 
 // ---------------------------------------------------------------- Fq2 runs (G2 groups)

@@ -193,7 +193,10 @@ __global__ void __launch_bounds__(64) k_test_run28(const uint32_t* in, uint32_t*
         uint32_t X = x, Y = y, Z = z;
         jac_dbl_run28<P>(e, X, Y, Z, c);
         uint32_t X2 = x, Y2 = y, Z2 = z;
-        for (int i = 0; i < c; ++i) jac_dbl_wide<P>(e, X2, Y2, Z2);
+        for (int i = 0; i < c; ++i) {
+            if constexpr (WideEnv<P>::ROW == 16) jac_dbl_wide<P>(e, X2, Y2, Z2);
+            else jac_dbl_wide2<P>(e, X2, Y2, Z2);
+        }
         if (threadIdx.x < (unsigned)N) {
             uint32_t* o = out_run + (size_t)t * 3 * N;
             uint32_t* r = out_ref + (size_t)t * 3 * N;
@@ -491,6 +494,7 @@ int main() {
     int bad = run<alt_bn128_fq>("alt_bn128_fq") + run<bls12_377_fq>("bls12_377_fq") + run<bw6_761_fq>("bw6_761_fq");
     bad += run2<alt_bn128_fq, -1>("alt_bn128_fq2") + run2<bls12_377_fq, -5>("bls12_377_fq2");
     bad += run28<alt_bn128_fq>("alt_bn128_fq") + run28<bls12_377_fq>("bls12_377_fq") + run28<bls12_381_fq>("bls12_381_fq");
+    bad += run28<bw6_761_fq>("bw6_761_fq");
     bad += run28q<alt_bn128_fq, -1>("alt_bn128_fq2") + run28q<bls12_377_fq, -5>("bls12_377_fq2") + run28q<bls12_381_fq, -1>("bls12_381_fq2");
     printf(bad ? "WIDE TEST FAILED\n" : "WIDE TEST PASSED\n");
     return bad ? 1 : 0;
