@@ -1308,50 +1308,65 @@ __global__ void __launch_bounds__(256) k_sum_block(const uint32_t* __restrict__ 
     if (lane < (uint32_t)RED_LANES) store_jac(out + w * XYZW, p);
 }
 
-// The same for prime-field groups of up to 15 words, with the last levels on lane-split elements:
-// a per-lane addition costs a lone wave ~14 us however few lanes are live, a jac_add_wide ~3.5 us, so
-// once few points per window remain it is faster to give every wave one addition at a time.  Every
-// wave first folds groups of 4 per-lane (two levels), the up to 64 partial sums go to LDS, and the
-// eight waves of the workgroup then halve them round by round (ping-pong LDS buffers).  out[w].
-constexpr bool SUM_WIDE = GP::DEG == 1 && FQ::N < 16;
-constexpr int SUMW_THREADS = 512, SUMW_SLOTS = SUMW_THREADS / 4;
+// The same with the last levels on lane-split elements: a per-lane addition costs a lone wave its
+// whole latency however few lanes are live (~14 us for 8 words, ~40 us for Fq2 over 12, ~125 us for
+// 24 words), a lane-split addition a quarter to a sixth of that, so once few points per window
+// remain it is faster to give every wave one addition at a time.  Every wave first folds groups
+// of 4 per-lane (two levels), the partial sums go to LDS, and the waves of the workgroup then
+// halve them round by round (ping-pong LDS buffers).  out[w].
+constexpr int SUMW_THREADS = (GP::DEG == 1 && FQ::N < 16) ? 512 : 256;
+constexpr int SUMW_SLOTS = SUMW_THREADS / RED_LANES / 4;
+template <class Q = FQ>
+AMDMSM_DEV void sum_wide_add(const WideEnv<Q>& env, const uint32_t* a, const uint32_t* b, uint32_t* o) {
+    if constexpr (GP::DEG == 2) {
+        using F = WideFq2<Q, (GP::NR_SMALL == 0 ? -1 : GP::NR_SMALL)>;
+        const uint32_t wi = F::word_index(env);
+        uint32_t X1 = env.valid ? a[wi] : 0u, Y1 = env.valid ? a[EW + wi] : 0u, Z1 = env.valid ? a[2 * EW + wi] : 0u;
+        const uint32_t X2 = env.valid ? b[wi] : 0u, Y2 = env.valid ? b[EW + wi] : 0u, Z2 = env.valid ? b[2 * EW + wi] : 0u;
+        jac_add_seq<F, Q>(env, X1, Y1, Z1, X2, Y2, Z2);
+        if (((threadIdx.x & 63u) >> 4) < 2 && env.valid) {
+            o[wi] = X1;
+            o[EW + wi] = Y1;
+            o[2 * EW + wi] = Z1;
+        }
+    } else {
+        uint32_t X1 = env.valid ? a[env.j] : 0u, Y1 = env.valid ? a[EW + env.j] : 0u, Z1 = env.valid ? a[2 * EW + env.j] : 0u;
+        const uint32_t X2 = env.valid ? b[env.j] : 0u, Y2 = env.valid ? b[EW + env.j] : 0u, Z2 = env.valid ? b[2 * EW + env.j] : 0u;
+        if constexpr (Q::N < 16) jac_add_wide<Q>(env, X1, Y1, Z1, X2, Y2, Z2);
+        else jac_add_seq<WideFq<Q>, Q>(env, X1, Y1, Z1, X2, Y2, Z2);
+        if ((threadIdx.x & 63u) < (uint32_t)Q::N) {
+            o[env.j] = X1;
+            o[EW + env.j] = Y1;
+            o[2 * EW + env.j] = Z1;
+        }
+    }
+}
 __global__ void __launch_bounds__(SUMW_THREADS) k_sum_block_wide(const uint32_t* __restrict__ in, int W, uint32_t M,
                                                                  uint32_t* __restrict__ out) {
-    if constexpr (SUM_WIDE) {
-        __shared__ uint32_t buf[2][SUMW_SLOTS * XYZW];
-        __builtin_amdgcn_s_setprio(3);
-        const size_t w = blockIdx.x;
-        const uint32_t i = threadIdx.x, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-        constexpr uint32_t NWAVES = SUMW_THREADS / 64;
-        Jac<E> p;
-        if (i < M) load_jac(p, in + (w * M + i) * XYZW); else jac_set_inf(p);
-        wave_group_sum(p, 4);
-        if ((lane & 3u) == 0) store_jac(buf[0] + (size_t)(i >> 2) * XYZW, p);
-        __syncthreads();
-        const WideEnv<FQ> env = wide_env<FQ>();
-        uint32_t K = (M + 3) / 4;   // partial sums (M is a power of two >= 4)
-        int cur = 0;
-        while (K > 1) {
-            const uint32_t pairs = K / 2;
-            for (uint32_t q = wave; q < pairs; q += NWAVES) {   // wave-uniform
-                const uint32_t* a = buf[cur] + (size_t)(2 * q) * XYZW;
-                const uint32_t* b = a + XYZW;
-                uint32_t X1 = env.valid ? a[env.j] : 0u, Y1 = env.valid ? a[EW + env.j] : 0u, Z1 = env.valid ? a[2 * EW + env.j] : 0u;
-                const uint32_t X2 = env.valid ? b[env.j] : 0u, Y2 = env.valid ? b[EW + env.j] : 0u, Z2 = env.valid ? b[2 * EW + env.j] : 0u;
-                jac_add_wide<FQ>(env, X1, Y1, Z1, X2, Y2, Z2);
-                if (lane < (uint32_t)FQ::N) {
-                    uint32_t* o = buf[cur ^ 1] + (size_t)q * XYZW;
-                    o[lane] = X1;
-                    o[EW + lane] = Y1;
-                    o[2 * EW + lane] = Z1;
-                }
-            }
-            __syncthreads();
-            cur ^= 1;
-            K = pairs;
+    __shared__ uint32_t buf[2][SUMW_SLOTS * XYZW];
+    __builtin_amdgcn_s_setprio(3);
+    const size_t w = blockIdx.x;
+    const uint32_t i = threadIdx.x / RED_LANES, wave = threadIdx.x >> 6;   // i: reduction lane
+    constexpr uint32_t NWAVES = SUMW_THREADS / 64;
+    Jac<ER> p;
+    if (i < M) load_jac(p, in + (w * M + i) * XYZW); else jac_set_inf(p);
+    wave_group_sum_r(p, 4);
+    if ((i & 3u) == 0) store_jac(buf[0] + (size_t)(i >> 2) * XYZW, p);
+    __syncthreads();
+    const WideEnv<FQ> env = wide_env<FQ>();
+    uint32_t K = (M + 3) / 4;   // partial sums (M is a power of two >= 8)
+    int cur = 0;
+    while (K > 1) {
+        const uint32_t pairs = K / 2;
+        for (uint32_t q = wave; q < pairs; q += NWAVES) {   // wave-uniform
+            const uint32_t* a = buf[cur] + (size_t)(2 * q) * XYZW;
+            sum_wide_add(env, a, a + XYZW, buf[cur ^ 1] + (size_t)q * XYZW);
         }
-        if (threadIdx.x < (uint32_t)XYZW) out[w * XYZW + threadIdx.x] = buf[cur][threadIdx.x];
+        __syncthreads();
+        cur ^= 1;
+        K = pairs;
     }
+    for (uint32_t t = threadIdx.x; t < (uint32_t)XYZW; t += SUMW_THREADS) out[w * XYZW + t] = buf[cur][t];
 }
 
 // Horner over the window sums, high to low, c doublings between windows (multiexp.tcc:612-629),
@@ -2166,7 +2181,7 @@ void l_sum_butterfly(hipStream_t st, const uint32_t* in, int W, uint32_t M, uint
     hipLaunchKernelGGL(k_sum_butterfly, dim3(blocks_for((size_t)W * M * RED_LANES, 64)), dim3(64), 0, st, in, W, M, out);
 }
 void l_sum_block(hipStream_t st, const uint32_t* in, int W, uint32_t M, uint32_t* out) {
-    if (SUM_WIDE && M >= 8 && M <= (uint32_t)SUMW_THREADS && (M & (M - 1)) == 0) {
+    if (M >= 8 && M * RED_LANES <= (uint32_t)SUMW_THREADS && (M & (M - 1)) == 0) {
         hipLaunchKernelGGL(k_sum_block_wide, dim3(W), dim3(SUMW_THREADS), 0, st, in, W, M, out);
         return;
     }
