@@ -50,7 +50,7 @@ MAC_PAIR_PEAK = 33.15e12
 FQ_LIMBS = {0: 8, 1: 12, 2: 24, 3: 12}
 # (G1, as k_accumulate computes it: 10 multiplications but 9 Montgomery reductions -- Y3 is one fused sum of two
 # products -- of N^2 multiply-accumulate pairs each = 9.5 products; the Fq2 figure is the unfused upper bound)
-FQ_PRODUCTS_PER_MADD = {1: 9.5, 2: 28}
+FQ_PRODUCTS_PER_MADD = {1: 9.5, 2: 27}   # Fq2: 8 M x 6 N^2 + 2 S x 4 N^2 - 2 N^2 (fused Y3) = 54 N^2 pairs
 FR_MODULUS = {
     0: 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001,
     1: 0x12AB655E9A2CA55660B44D1E5C37B00159AA76FED00000010A11800000000001,
@@ -69,6 +69,9 @@ def parse_args():
     ap.add_argument("--curve", default="alt_bn128", choices=sorted(CURVES))
     ap.add_argument("--group", type=int, default=1, choices=(1, 2))
     ap.add_argument("--window-bits", type=int, default=0)
+    ap.add_argument("--endomorphism", type=int, default=0, choices=(-1, 0, 1, 2),
+                    help="amdmsm_opts.endomorphism of the `value` workload: 0 = the split only where the whole curve group "
+                         "has order r (alt_bn128 G1), 1 = permitted (the synthetic bases are multiples of the generator)")
     ap.add_argument("--cpu-log2n", type=int, default=20, help="size of the cpu_baseline workload")
     ap.add_argument("--extra-log2n", type=int, default=int(os.environ.get("AMDMSM_BENCH_EXTRA_LOG2N", "26")),
                     help="N = 1: also time this size (config.legs.points_2pXX); 0 disables")
@@ -82,6 +85,8 @@ def parse_args():
     ap.add_argument("--precomputed-c", type=int, default=16,
                     help="N = 1: also time the precomputed-multiples MSM (multi_exp_stream_with_precompute's algorithm "
                          "on an HBM-resident table of [2^(jc)]P) with this window size; 0 disables")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="N = 1: skip the configs[2] / configs[4] legs (bls12_377 G1 2^22; bw6_761 G1 + bls12_377 G2 at 2^21 and 2^24)")
     ap.add_argument("--config4-log2n", type=int, default=24, help="N > 1: total points of the configs[4] leg; 0 disables")
     return ap.parse_args()
 
@@ -160,7 +165,7 @@ def pmc_traffic(curve_name, group, log2n, window_bits):
     gfx950 correction 2*FETCH + WRITE, see the file), or None when no pass matches the workload."""
     import glob
 
-    best = None
+    best, src = None, None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*pmc*.json"))):
         try:
             d = json.load(open(path))
@@ -169,9 +174,10 @@ def pmc_traffic(curve_name, group, log2n, window_bits):
                 continue
             k = d["kernels"]["k_accumulate"]
             best = (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0
+            src = os.path.relpath(path, ROOT)
         except Exception:
             continue
-    return best
+    return best, src
 
 
 def cpu_model():
@@ -293,6 +299,7 @@ def roofline_of(curve_name, curve, group, n_launch, plan, acc_ms, log2n_for_pmc)
     columns = 2 if plan.get("endomorphism") else 1
     lane_instr = float(n_launch) * columns * plan["num_windows"] * fq_products * 4 * FQ_LIMBS[curve] ** 2
     mac_rate = lane_instr / (acc_ms * 1e-3)
+    traffic, traffic_src = pmc_traffic(curve_name, group, log2n_for_pmc, plan["c"]) if log2n_for_pmc else (None, None)
     return {
         "bound": "hbm",
         "kernel": "k_accumulate (bucket accumulation)",
@@ -300,7 +307,10 @@ def roofline_of(curve_name, curve, group, n_launch, plan, acc_ms, log2n_for_pmc)
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS,
-        "traffic": pmc_traffic(curve_name, group, log2n_for_pmc, plan["c"]) if log2n_for_pmc else None,
+        "traffic": traffic,
+        "traffic_source": (f"{traffic_src}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload committed with the "
+                           "build, (2*FETCH + WRITE) * 1024 per k_accumulate launch; not re-measured in this run")
+        if traffic_src else None,
         "algorithmic_bytes_per_launch": algo_bytes,
         "kernel_ms": acc_ms,
         "note": "integer-ALU bound path (no MFMA); HBM fraction is small by construction",
@@ -312,14 +322,96 @@ def roofline_of(curve_name, curve, group, n_launch, plan, acc_ms, log2n_for_pmc)
     }
 
 
+def baseline_tag(curve_name, group, log2n):
+    return {("alt_bn128", 1, 20): " (BASELINE configs[1])", ("bls12_377", 1, 22): " (BASELINE configs[2])",
+            ("alt_bn128", 1, 26): " (the north-star target size)", ("bw6_761", 1, 21): " (per-rank shard of BASELINE configs[4])",
+            ("bls12_377", 2, 21): " (per-rank shard of BASELINE configs[4])"}.get((curve_name, group, log2n), "")
+
+
 def mean_phases(phases):
     return {k: float(np.mean([p[k] for p in phases])) for k in phases[0]} if phases else {}
+
+
+def other_config_legs(args, tm, dev, device_index):
+    """The other single-GPU-sized BASELINE configurations, each with its phase times and its own
+    roofline (the reference's profiler runs G1 and G2 in one pass, profile_multiexp.cpp:401-414):
+      configs[2]   bls12_377 G1, 2^22 points;
+      configs[4]   bw6_761 G1 and bls12_377 G2: the per-rank shard of the 8-GPU run (2^21 points each),
+                   alone and issued together on two contexts (what a rank of `--gpus 8` does), and the
+                   2^24-point totals alone on this one GPU.
+    Bases (i+1)G are multiples of the generator, so the endomorphism split is permitted explicitly for
+    configs[4] (amdmsm_opts.endomorphism = 1), as in the N > 1 leg; configs[2] runs with the default."""
+    legs = {}
+    k = max(2, min(args.steps, 3))
+
+    def alone(eng, cname, group, log2n, endo, tag, what):
+        curve = CURVES[cname]
+        n = 1 << log2n
+        eng.endomorphism = endo
+        eng.set_timing(True)
+        plan = libff_amd.plan(curve, group, n, endomorphism=endo)
+        b, s = gen_inputs(eng, curve, group, 0, n, dev, 31 + log2n)
+        msm = ShardedMsm(eng, curve, group, depth=1)
+        e, ph = timed_msm(tm, eng, msm, b, s, n, k, 1)
+        acc = float(np.mean([p["accumulate_ms"] for p in ph]))
+        legs[tag] = {"workload": what, "steps": k, "value": n * k / e, "unit": "scalar-muls/s", "ms_per_step": e / k * 1e3,
+                     "window_bits": plan["c"], "num_windows": plan["num_windows"], "endomorphism_split": plan["endomorphism"],
+                     "phases_ms": mean_phases(ph), "roofline": roofline_of(cname, curve, group, n, plan, acc, log2n)}
+        return b, s, n
+
+    eng = libff_amd.Engine(device_index)
+    b, s, n = alone(eng, "bls12_377", 1, 22, 0, "config2_bls12_377_g1_2p22",
+                    "BASELINE configs[2]: bls12_377 G1 MSM (384-bit field), 2^22 points, 1 GPU")
+    del b, s
+    torch.cuda.empty_cache()
+    # configs[4], per-rank shard
+    eng2 = libff_amd.Engine(device_index)
+    b1, s1, n1 = alone(eng, "bw6_761", 1, 21, 1, "config4_shard_bw6_761_g1_2p21",
+                       "BASELINE configs[4], per-rank shard alone: bw6_761 G1 MSM, 2^21 points (2^24 over 8 GPUs)")
+    b2, s2, n2 = alone(eng2, "bls12_377", 2, 21, 1, "config4_shard_bls12_377_g2_2p21",
+                       "BASELINE configs[4], per-rank shard alone: bls12_377 G2 MSM, 2^21 points (2^24 over 8 GPUs)")
+    jobs = [(ShardedMsm(eng, 2, 1, depth=1), b1, s1, n1), (ShardedMsm(eng2, 1, 2, depth=1), b2, s2, n2)]
+
+    def both():
+        for m, bb, ss, nn in jobs:   # asynchronous: the two MSMs are in flight together
+            m.run(bb, ss, nn, libff_amd.OUT_LIBFF)
+
+    both()
+    for m, _, _, _ in jobs:
+        m.synchronize()
+    tm.fence()
+    t0 = time.perf_counter()
+    for _ in range(k):
+        both()
+    for m, _, _, _ in jobs:
+        m.synchronize()
+    tm.fence()
+    e = time.perf_counter() - t0
+    alone_ms = legs["config4_shard_bw6_761_g1_2p21"]["ms_per_step"] + legs["config4_shard_bls12_377_g2_2p21"]["ms_per_step"]
+    legs["config4_shard_pair_together"] = {
+        "workload": "BASELINE configs[4], what one rank of the 8-GPU run does: bw6_761 G1 2^21 + bls12_377 G2 2^21 issued together "
+                    "on two contexts (two streams); a step = both MSMs", "steps": k, "value": (n1 + n2) * k / e,
+        "unit": "scalar-muls/s", "ms_per_step": e / k * 1e3, "one_after_the_other_ms": alone_ms}
+    del jobs, b1, s1, b2, s2
+    torch.cuda.empty_cache()
+    # configs[4], the stated totals on one GPU
+    b, s, n = alone(eng, "bw6_761", 1, 24, 1, "config4_total_bw6_761_g1_2p24",
+                    "BASELINE configs[4] at its stated total on ONE GPU: bw6_761 G1 MSM, 2^24 points")
+    del b, s
+    torch.cuda.empty_cache()
+    b, s, n = alone(eng2, "bls12_377", 2, 24, 1, "config4_total_bls12_377_g2_2p24",
+                    "BASELINE configs[4] at its stated total on ONE GPU: bls12_377 G2 MSM, 2^24 points")
+    del b, s
+    torch.cuda.empty_cache()
+    eng.close()
+    eng2.close()
+    return legs
 
 
 def single_gpu(args, tm, eng, dev, curve, group):
     log2n = args.log2n or 20
     n = 1 << log2n
-    plan = libff_amd.plan(curve, group, n, args.window_bits)
+    plan = libff_amd.plan(curve, group, n, args.window_bits, endomorphism=args.endomorphism)
     sz = libff_amd.sizes(curve, group)
     bases, scalars = gen_inputs(eng, curve, group, 0, n, dev, 1234)
     msm = ShardedMsm(eng, curve, group, depth=max(1, args.pipeline))
@@ -410,7 +502,7 @@ def single_gpu(args, tm, eng, dev, curve, group):
         bases2, scalars2 = gen_inputs(eng, curve, group, 0, n2, dev, 4321)
         k2 = 4
         e2, ph2 = timed_msm(tm, eng, msm, bases2, scalars2, n2, k2, 1)
-        p2 = libff_amd.plan(curve, group, n2)
+        p2 = libff_amd.plan(curve, group, n2, endomorphism=args.endomorphism)
         acc2 = float(np.mean([p["accumulate_ms"] for p in ph2]))
         legs[f"points_2p{args.extra_log2n}"] = {
             "workload": f"{args.curve} G{group} MSM, 2^{args.extra_log2n} points on one GPU (the north-star target size)",
@@ -419,11 +511,16 @@ def single_gpu(args, tm, eng, dev, curve, group):
             "phases_ms": mean_phases(ph2)}
         roof2 = roofline_of(args.curve, curve, group, n2, p2, acc2, args.extra_log2n)
         del bases2, scalars2
+        torch.cuda.empty_cache()
+
+    # ---- the other BASELINE configurations that fit one GPU (configs[2], configs[4]) ----
+    if not args.no_legs and not args.no_other_configs and (args.curve, group) == ("alt_bn128", 1):
+        legs.update(other_config_legs(args, tm, dev, eng.device))
 
     roof = roofline_of(args.curve, curve, group, n, plan, acc, log2n)
     if roof2 is not None:
-        roof[f"at_2p{args.extra_log2n}"] = {k: roof2[k] for k in ("achieved", "frac", "traffic", "algorithmic_bytes_per_launch",
-                                                                  "kernel_ms", "mac_issue")}
+        roof[f"at_2p{args.extra_log2n}"] = {k: roof2[k] for k in ("achieved", "frac", "traffic", "traffic_source",
+                                                                  "algorithmic_bytes_per_launch", "kernel_ms", "mac_issue")}
     out = {
         "metric": "G1 MSM throughput (scalar-muls/sec)" if group == 1 else "G2 MSM throughput (scalar-muls/sec)",
         "value": n * args.steps / elapsed,
@@ -438,7 +535,7 @@ def single_gpu(args, tm, eng, dev, curve, group):
         "dtype": "u32",
         "data": "synthetic",
         "config": {
-            "workload": f"{args.curve} G{group} MSM, 2^{log2n} points, 1 GPU (BASELINE configs[1]); bases (i+1)G affine "
+            "workload": f"{args.curve} G{group} MSM, 2^{log2n} points, 1 GPU{baseline_tag(args.curve, group, log2n)}; bases (i+1)G affine "
                         f"resident in HBM, uniform random scalars in [0,r) (Montgomery residues as libff holds them)",
             "points_per_gpu": n,
             "total_points": n,
@@ -461,13 +558,27 @@ def multi_gpu(args, tm, eng, dev, rank, world, curve, group):
     total = 1 << log2n
     lo, hi = shard_range(total, world, rank)
     n = hi - lo
-    plan = libff_amd.plan(curve, group, n, args.window_bits)
+    plan = libff_amd.plan(curve, group, n, args.window_bits, endomorphism=args.endomorphism)
     bases, scalars = gen_inputs(eng, curve, group, lo, n, dev, 1234 + rank)   # bases (lo + i + 1) * G
     msm = ShardedMsm(eng, curve, group, depth=1)
     eng.set_timing(True)
     elapsed, phases = timed_msm(tm, eng, msm, bases, scalars, n, args.steps, args.warmup, args.window_bits)
     acc = float(np.mean([p["accumulate_ms"] for p in phases]))
     legs = {}
+    # What the step should cost: this rank's shard MSM alone (HIP events around its kernels, max over
+    # ranks) + the exchange (all-gather of the partial points + k_sum_points), timed on its own.
+    shard_ms = tm.max_over_ranks(float(np.mean([p["total_ms"] for p in phases])) * 1e-3) * 1e3
+    kx = 20
+    for _ in range(3):
+        msm.exchange_only(libff_amd.OUT_LIBFF)
+    msm.synchronize()
+    tm.fence()
+    tx = time.perf_counter()
+    for _ in range(kx):
+        msm.exchange_only(libff_amd.OUT_LIBFF)
+    msm.synchronize()
+    tm.fence()
+    exchange_ms = tm.max_over_ranks(time.perf_counter() - tx) / kx * 1e3
 
     # the same total on rank 0 alone (what one GPU does with the whole input), the others wait
     if not args.no_legs:
@@ -568,6 +679,12 @@ def multi_gpu(args, tm, eng, dev, rank, world, curve, group):
                            "+ local sum",
             "msms_in_flight": 1,
             "phases_ms": mean_phases(phases),
+            "shard_ms": shard_ms,
+            "exchange_ms": exchange_ms,
+            "predicted_ms": shard_ms + exchange_ms,
+            "predicted_note": "ms_per_step should equal shard_ms (the slowest rank's MSM over its 2^log2n / N points, HIP events) "
+                              "+ exchange_ms (RCCL all-gather of N partial points + k_sum_points, timed back to back on its own); "
+                              "DESIGN.md section 5 states the expected strong-scaling curve",
             "legs": legs,
         },
         "roofline": roofline_of(args.curve, curve, group, n, plan, acc, 0),
@@ -598,7 +715,7 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     curve, group = CURVES[args.curve], args.group
-    eng = libff_amd.Engine(local_rank)
+    eng = libff_amd.Engine(local_rank, endomorphism=args.endomorphism)
     tm = Timer(world, dev)
     if world == 1:
         out = single_gpu(args, tm, eng, dev, curve, group)

@@ -74,19 +74,28 @@ enum {
 
 typedef struct amdmsm_ctx amdmsm_ctx;
 
+/* Version of this header's structure layouts and entry points; amdmsm_abi_version() returns the value the
+ * loaded library was built with.  3: amdmsm_opts starts with struct_size. */
+#define AMDMSM_ABI_VERSION 3
+
 typedef struct amdmsm_opts {
+    uint32_t struct_size; /* = sizeof(amdmsm_opts) of the header the caller was compiled against (AMDMSM_OPTS_INIT);
+                             a value the library does not know is refused with AMDMSM_ERR_BAD_ARG, so a caller built
+                             against another layout fails loudly instead of having its fields misread */
     int window_bits;   /* c; 0 = engine picks (see amdmsm_plan) */
     int segment_len;   /* L for the bucket reduction; 0 = auto */
     int out_form;      /* AMDMSM_OUT_* ; host entry points default to AMDMSM_OUT_LIBFF */
     int scalars_plain; /* nonzero: scalars are plain bigints, not Montgomery residues */
-    void *stream;      /* hipStream_t to launch on (device entry points); NULL = context stream */
     int endomorphism;  /* k P as k1 P + k2 phi(P), phi(x, y) = (beta x, y), half-length k1, k2: half the windows
                           (bucket reduction and final doublings).  Exact where phi = [lambda], i.e. on the order-r
                           subgroup libff's G1 / G2 are.  0 = permitted only where the whole curve group has order r
                           (alt_bn128 G1), 1 = permitted: the caller guarantees every base lies in that subgroup,
                           2 = same guarantee, used at every size, -1 = never.  Where permitted the engine uses it
                           when it pays (below ~2^22 points; amdmsm_plan_ex tells) */
+    void *stream;      /* hipStream_t to launch on (device entry points); NULL = context stream */
 } amdmsm_opts;
+/* amdmsm_opts o = AMDMSM_OPTS_INIT;  -- every other field zero (= defaults) */
+#define AMDMSM_OPTS_INIT { (uint32_t)sizeof(amdmsm_opts) }
 
 #define AMDMSM_MAX_PHASES 8
 /* phase indices of amdmsm_get_timings */
@@ -99,6 +108,7 @@ enum {
     AMDMSM_PH_TOTAL = 5
 };
 
+int amdmsm_abi_version(void);
 int amdmsm_device_count(void);
 int amdmsm_ctx_create(int device, amdmsm_ctx **out);
 void amdmsm_ctx_destroy(amdmsm_ctx *ctx);
@@ -164,6 +174,12 @@ int amdmsm_invalidate_bases(amdmsm_ctx *ctx, const void *host_ptr, size_t bytes)
 int amdmsm_multi_exp_multi(amdmsm_ctx *const *ctxs, int ndev, int curve, int group,
                            const void *bases_xyz, size_t base_stride_bytes, int base_form,
                            const void *scalars, size_t n, void *out_xyz, const amdmsm_opts *opts);
+/* multi_exp_filter_one_zero (multiexp.tcc:690-757) over the same device split: every device classifies the
+ * scalars of its own range, the three counts are added up (stats may be NULL = amdmsm_multi_exp_multi) */
+int amdmsm_multi_exp_filter_one_zero_multi(amdmsm_ctx *const *ctxs, int ndev, int curve, int group,
+                                           const void *bases_xyz, size_t base_stride_bytes, int base_form,
+                                           const void *scalars, size_t n, void *out_xyz,
+                                           const amdmsm_opts *opts, size_t stats[3]);
 
 /* Streaming MSM: bases are pulled through `read` in libff's on-disk format -- binary,
  * Montgomery form, uncompressed, i.e. consecutive group_write<encoding_binary, form_montgomery,
@@ -252,7 +268,10 @@ int amdmsm_msm_precomputed_device(amdmsm_ctx *ctx, int curve, int group, const v
                                   void *d_out_xyz, const amdmsm_opts *opts);
 /* the device-resident form of amdmsm_multi_exp_multi: d_bases_affine[k] / d_scalars[k] / counts[k]
  * live on ctxs[k]'s device; the result is written to d_out_xyz_dev0 on ctxs[0]'s device
- * (opts->stream orders that final sum on device 0; the call returns after it has completed) */
+ * (opts->stream, a stream of ctxs[0]'s device: inputs produced on it are ordered before every range, and
+ * the final sum runs on it; the call returns after that sum has completed).
+ * Any entry point given more than 2^28 points (AMDMSM_MAX_RANGE_POINTS) runs them as contiguous ranges
+ * whose partial results are summed -- the reference's chunk loop, multiexp.tcc:655-687. */
 int amdmsm_msm_device_multi(amdmsm_ctx *const *ctxs, int ndev, int curve, int group,
                             const void *const *d_bases_affine, const void *const *d_scalars,
                             const size_t *counts, void *d_out_xyz_dev0, const amdmsm_opts *opts);

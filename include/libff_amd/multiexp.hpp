@@ -164,7 +164,7 @@ GroupT gpu_multi_exp_inner(
     const size_t n = bases_end - bases;
     (void)exponents_end;
     GroupT result = GroupT::zero();
-    amdmsm_opts opts = {};
+    amdmsm_opts opts = AMDMSM_OPTS_INIT;
     opts.out_form = AMDMSM_OUT_LIBFF;
     opts.endomorphism = endomorphism_mode();
     const int rc = amdmsm_multi_exp(
@@ -210,7 +210,7 @@ GroupT gpu_multi_exp(
         --ndev;
     }
     GroupT result = GroupT::zero();
-    amdmsm_opts opts = {};
+    amdmsm_opts opts = AMDMSM_OPTS_INIT;
     opts.out_form = AMDMSM_OUT_LIBFF;
     opts.endomorphism = endomorphism_mode();
     const void *b = n ? static_cast<const void *>(&*vec_start) : nullptr;
@@ -219,17 +219,17 @@ GroupT gpu_multi_exp(
                          ? AMDMSM_FORM_SPECIAL
                          : AMDMSM_FORM_NORMAL;
     int rc;
-    if (stats) {
-        // counts come from device 0 over the whole scalar vector; the sum may still be split
+    if (ndev > 1) {
+        // stats != nullptr: every device classifies the scalars of its own range, counts added up
+        rc = amdmsm_multi_exp_filter_one_zero_multi(
+            ctxs.data(), (int)ndev, group_id<GroupT>::curve,
+            group_id<GroupT>::group, b, sizeof(GroupT), form, s, n,
+            static_cast<void *>(&result.X), &opts, stats);
+    } else if (stats) {
         rc = amdmsm_multi_exp_filter_one_zero(
             ctxs[0], group_id<GroupT>::curve, group_id<GroupT>::group, b,
             sizeof(GroupT), form, s, n, static_cast<void *>(&result.X), &opts,
             stats);
-    } else if (ndev > 1) {
-        rc = amdmsm_multi_exp_multi(
-            ctxs.data(), (int)ndev, group_id<GroupT>::curve,
-            group_id<GroupT>::group, b, sizeof(GroupT), form, s, n,
-            static_cast<void *>(&result.X), &opts);
     } else {
         rc = amdmsm_multi_exp(
             ctxs[0], group_id<GroupT>::curve, group_id<GroupT>::group, b,

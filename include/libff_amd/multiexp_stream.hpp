@@ -34,7 +34,7 @@ GroupT gpu_multi_exp_stream(
     const bool compressed = false)
 {
     GroupT result = GroupT::zero();
-    amdmsm_opts opts = {};
+    amdmsm_opts opts = AMDMSM_OPTS_INIT;
     opts.out_form = AMDMSM_OUT_LIBFF;
     opts.endomorphism = endomorphism_mode();
     const int rc = (compressed ? amdmsm_multi_exp_stream_compressed
@@ -65,7 +65,7 @@ GroupT gpu_multi_exp_stream_with_precompute(
     const size_t precompute_c)
 {
     GroupT result = GroupT::zero();
-    amdmsm_opts opts = {};
+    amdmsm_opts opts = AMDMSM_OPTS_INIT;
     opts.out_form = AMDMSM_OUT_LIBFF;
     const int rc = amdmsm_multi_exp_stream_with_precompute(
         default_context(),

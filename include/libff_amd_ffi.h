@@ -20,9 +20,13 @@
  * exact sizes, every integer < its modulus, is_well_formed(), is_in_safe_subgroup().  On any
  * failure the function returns false and leaves `out_g1` untouched.
  *
- * The symbols bls12_377_init / bw6_761_init etc. of ffi.h are NOT redefined here, so this
- * library can be loaded next to libff-ffi.  No init call is needed for the functions below;
- * amdmsm_ffi_set_device() optionally selects the GPU (default 0) before the first call.
+ * The reference's own <curve>_init / <curve>_g1_add / <curve>_g1_mul (ffi.h:19-38, 61-80) are exported
+ * too, device-backed and with the reference's reads and writes, so that an FFI host can load this one
+ * library; <curve>_pairing is not (pairings are outside this engine: a host that needs them loads
+ * libff-ffi for it).  A build with AMDMSM_FFI_NO_REFERENCE_SYMBOLS=1 in the environment
+ * (python -m libff_amd.build) leaves those six names out, so that the library can be linked or
+ * loaded next to libff-ffi without duplicate definitions.  No init call is needed for the *_multiexp
+ * functions; amdmsm_ffi_set_device() optionally selects the GPU (default 0) before the first call.
  */
 #ifndef LIBFF_AMD_FFI_H
 #define LIBFF_AMD_FFI_H
@@ -34,6 +38,22 @@ extern "C" {
 #endif
 
 bool amdmsm_ffi_set_device(int device);
+
+#ifndef AMDMSM_FFI_NO_REFERENCE_SYMBOLS
+/* ffi/ffi.h:19-38 (bls12_377: Fr 32 B, G1 96 B) and :61-80 (bw6_761: Fr 48 B, G1 192 B); ffi.cpp:16-54.
+ * *_init: true once the engine context exists on the selected GPU (the reference initialises its curve
+ * parameters here; the engine's are compile-time constants). */
+bool bls12_377_init(void);
+bool bls12_377_g1_add(const void *a_g1, size_t a_g1_size, const void *b_g1, size_t b_g1_size, void *out_g1,
+                      size_t out_g1_size);
+bool bls12_377_g1_mul(const void *p_g1, size_t p_g1_size, const void *s_fr, size_t s_fr_size, void *out_g1,
+                      size_t out_g1_size);
+bool bw6_761_init(void);
+bool bw6_761_g1_add(const void *a_g1, size_t a_g1_size, const void *b_g1, size_t b_g1_size, void *out_g1,
+                    size_t out_g1_size);
+bool bw6_761_g1_mul(const void *p_g1, size_t p_g1_size, const void *s_fr, size_t s_fr_size, void *out_g1,
+                    size_t out_g1_size);
+#endif
 
 bool alt_bn128_g1_multiexp(const void *bases_g1, size_t bases_g1_size, const void *scalars_fr,
                            size_t scalars_fr_size, void *out_g1, size_t out_g1_size);

@@ -13,7 +13,7 @@ from .engine import (  # noqa: F401
     ALT_BN128, BLS12_377, BLS12_381, BW6_761, G1, G2, OUT_AFFINE, OUT_JACOBIAN, OUT_LIBFF, AmdMsmError, Engine,
     bdlo12_signed_optimal_c, load_library, multi_exp_base_form_normal, multi_exp_base_form_special,
     multi_exp_method_BDLO12, multi_exp_method_BDLO12_signed, multi_exp_method_bos_coster,
-    multi_exp_method_naive, multi_exp_method_naive_plain, multi_exp_multi, msm_device_multi, pippenger_optimal_c, plan, precompute_num_digits, sizes,
+    multi_exp_method_naive, multi_exp_method_naive_plain, multi_exp_multi, multi_exp_filter_one_zero_multi, msm_device_multi, pippenger_optimal_c, plan, precompute_num_digits, sizes,
     endomorphism_info)
 
 __all__ = [
@@ -21,6 +21,6 @@ __all__ = [
     "AmdMsmError", "Engine", "bdlo12_signed_optimal_c", "load_library", "multi_exp_base_form_normal",
     "multi_exp_base_form_special", "multi_exp_method_BDLO12", "multi_exp_method_BDLO12_signed",
     "multi_exp_method_bos_coster", "multi_exp_method_naive", "multi_exp_method_naive_plain", "multi_exp_multi",
-    "msm_device_multi",
+    "multi_exp_filter_one_zero_multi", "msm_device_multi",
     "pippenger_optimal_c", "plan", "precompute_num_digits", "sizes", "endomorphism_info",
 ]

@@ -91,19 +91,27 @@ def build(force=False, verbose=True, jobs=None):
         if force or _newer(o, DEVICE_DEPS):
             tasks.append([cc, *COMMON, "-c", os.path.join(CSRC, "msm_group.hip"),
                           f"-DAMDMSM_GROUP={g}", f"-DAMDMSM_VT=vt_{g}", *GROUP_FLAGS.get(g, []), *extra, "-o", o])
+    # AMDMSM_FFI_NO_REFERENCE_SYMBOLS=1: leave out the reference's own FFI names (<curve>_init / _g1_add /
+    # _g1_mul, include/libff_amd_ffi.h) so that the library can sit next to libff-ffi
+    no_ref = os.environ.get("AMDMSM_FFI_NO_REFERENCE_SYMBOLS", "0") not in ("", "0")
     for src in ("engine", "ffi"):
-        eo = os.path.join(OBJ, f"{src}.o")
+        eo = os.path.join(OBJ, f"{src}{'_noref' if no_ref and src == 'ffi' else ''}.o")
         objs.append(eo)
         if force or _newer(eo, HOST_DEPS):
-            tasks.append([cc, *COMMON, "-x", "hip", "-c", os.path.join(CSRC, f"{src}.cpp"), "-o", eo])
+            tasks.append([cc, *COMMON, *(["-DAMDMSM_FFI_NO_REFERENCE_SYMBOLS=1"] if no_ref and src == "ffi" else []),
+                          "-x", "hip", "-c", os.path.join(CSRC, f"{src}.cpp"), "-o", eo])
     if tasks:
         if verbose:
             print(f"[libff_amd.build] compiling {len(tasks)} translation unit(s) for {ARCH} ...", flush=True)
         jobs = jobs or min(len(tasks), max(1, (os.cpu_count() or 2) - 1))
         with concurrent.futures.ThreadPoolExecutor(max_workers=jobs) as ex:
             list(ex.map(_run, tasks))
-    if tasks or not os.path.exists(SO_PATH):
+    if tasks or not os.path.exists(SO_PATH) or no_ref != os.path.exists(SO_PATH + ".noref"):
         _run([cc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-Wl,-soname,libamdmsm.so", "-o", SO_PATH, *objs])
+        if no_ref:
+            open(SO_PATH + ".noref", "w").close()   # marker: this link carries no reference FFI names
+        elif os.path.exists(SO_PATH + ".noref"):
+            os.remove(SO_PATH + ".noref")
         if verbose:
             print(f"[libff_amd.build] linked {SO_PATH}", flush=True)
     return SO_PATH

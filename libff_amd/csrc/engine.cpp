@@ -60,6 +60,9 @@ struct base_entry {
     void *d_endo = nullptr;   // phi(P) records of the whole vector (endomorphism split), built at first use
     bool automatic = false;   // created by AMDMSM_BASE_CACHE, evictable
     uint64_t last_use = 0;
+    size_t aff_bytes = 0;     // bytes of one compact affine record of this entry's group
+    // HBM held by the entry: the affine copy and, once built, the phi(P) records
+    size_t bytes() const { return n * aff_bytes * (d_endo ? 2 : 1); }
 };
 
 struct amdmsm_ctx {
@@ -366,23 +369,29 @@ void record(amdmsm_ctx *ctx, ws_slot &sl, int idx, hipStream_t st) {
 // caller guarantees subgroup membership of every base (libff's G1 / G2 are that subgroup; the FFI
 // entry points check it while decoding), 2 = the same guarantee, and use it whatever the size,
 // -1 = never.  Where permitted it is used when the cost model favours it (plan_cost).
-// AMDMSM_GLV=off|auto|on|force overrides the option (experiments).
+// AMDMSM_GLV=off switches it off everywhere; AMDMSM_GLV=on|force apply only where the caller left
+// the option at 0 (experiments; logged once) -- a caller's -1 is never overridden.
 bool use_endomorphism(const group_vtable *vt, size_t n, const amdmsm_opts *opts, int table_digits) {
     static const int env = [] {
         const char *e = getenv("AMDMSM_GLV");
+        int v = 0;
         if (!e) return 0;
-        if (!strcmp(e, "off") || !strcmp(e, "0")) return -1;
-        if (!strcmp(e, "on") || !strcmp(e, "1")) return 1;
-        if (!strcmp(e, "all") || !strcmp(e, "force") || !strcmp(e, "2")) return 2;
-        if (!strcmp(e, "auto")) return 3;
-        return 0;
+        if (!strcmp(e, "off") || !strcmp(e, "0")) v = -1;
+        else if (!strcmp(e, "on") || !strcmp(e, "1")) v = 1;
+        else if (!strcmp(e, "all") || !strcmp(e, "force") || !strcmp(e, "2")) v = 2;
+        else if (!strcmp(e, "auto")) v = 3;
+        if (v) fprintf(stderr, "[amdmsm] AMDMSM_GLV=%s overrides amdmsm_opts.endomorphism where the caller left it at 0 "
+                               "(off: everywhere); on / force assert that every base lies in the order-r subgroup\n", e);
+        return v;
     }();
     if (table_digits || n == 0 || n >= ((size_t)1 << 30)) return false;
     const int c_req = opts ? opts->window_bits : 0;
     if (c_req > 22) return false;
     int want = opts ? opts->endomorphism : 0;
-    if (env == -1 || env == 1 || env == 2) want = env;
-    if (env == 3) want = 0;
+    // The environment may switch the split off everywhere, and otherwise speaks only where the caller
+    // expressed no choice (0): a caller's -1 (never) stays never, a caller's 1 / 2 keeps its meaning.
+    if (env == -1) want = -1;
+    else if ((env == 1 || env == 2) && want == 0) want = env;
     if (want < 0 || (want == 0 && !vt->prime_order)) return false;
     if (want >= 2) return true;
     // permitted: used where the model says it pays (small and medium inputs)
@@ -395,6 +404,32 @@ bool use_endomorphism(const group_vtable *vt, size_t n, const amdmsm_opts *opts,
         choose_c(vt, n, true, &split);
     }
     return split < 0.98 * full;
+}
+
+int check_opts(amdmsm_ctx *ctx, const amdmsm_opts *opts) {
+    if (opts && opts->struct_size != sizeof(amdmsm_opts))
+        return fail(ctx, AMDMSM_ERR_BAD_ARG, "amdmsm_opts.struct_size does not match this library (AMDMSM_ABI_VERSION " +
+                                                 std::to_string(AMDMSM_ABI_VERSION) + "): initialise with AMDMSM_OPTS_INIT");
+    return AMDMSM_OK;
+}
+#define CHECK_OPTS(ctx, opts)                       \
+    do {                                            \
+        const int rc_opts_ = check_opts(ctx, opts); \
+        if (rc_opts_) return rc_opts_;              \
+    } while (0)
+
+// One MSM handles at most this many points (its sorted lists index points with 31 bits, and the
+// workspace grows with n: 42 GiB at 2^28 alt_bn128 points); longer inputs are cut into contiguous
+// ranges whose partial results are summed, exactly the reference's chunk loop (multiexp.tcc:655-687).
+// AMDMSM_MAX_RANGE_POINTS lowers the limit so that tests reach the split with small inputs.
+constexpr size_t MAX_RANGES = 64;
+size_t max_range_points() {
+    static const size_t v = [] {
+        const char *e = getenv("AMDMSM_MAX_RANGE_POINTS");
+        const long long x = e ? atoll(e) : 0;
+        return x > 0 ? (size_t)x : (size_t)1 << 28;
+    }();
+    return v;
 }
 
 struct msm_hook {
@@ -533,12 +568,51 @@ int msm_device_impl(amdmsm_ctx *ctx, const group_vtable *vt, const uint32_t *d_b
     return AMDMSM_OK;
 }
 
+int ensure_partials(amdmsm_ctx *ctx) {
+    if (!ctx->chunk_partials) HIP_TRY(ctx, hipMalloc(&ctx->chunk_partials, MAX_RANGES * 3 * 24 * 2 * 4));
+    return AMDMSM_OK;
+}
+
+// Device-resident MSM of any length: one msm_device_impl, or -- above max_range_points() -- the
+// reference's chunk loop (multiexp.tcc:655-687: `one = total / chunks`, the last range takes the
+// remainder, partial results summed) with ranges run one after the other on the caller's stream.
+int msm_device_ranges(amdmsm_ctx *ctx, const group_vtable *vt, const uint32_t *d_bases, const uint32_t *d_scalars, size_t n,
+                      uint32_t *d_out, const amdmsm_opts *opts) {
+    const size_t maxr = max_range_points();
+    if (n <= maxr) return msm_device_impl(ctx, vt, d_bases, d_scalars, n, d_out, opts);
+    const size_t parts = (n + maxr - 1) / maxr;
+    if (parts > MAX_RANGES) return fail(ctx, AMDMSM_ERR_TOO_LARGE, "input too large for one call");
+    const size_t one = n / parts;
+    const size_t xyz_bytes = (size_t)vt->el_words * 12, aff_bytes = (size_t)vt->el_words * 8, fr_bytes = (size_t)vt->fr_words * 4;
+    int rc = ensure_partials(ctx);
+    if (rc) return rc;
+    amdmsm_opts o = AMDMSM_OPTS_INIT;
+    if (opts) o = *opts;
+    else o.out_form = AMDMSM_OUT_LIBFF;
+    const int form = o.out_form;
+    o.out_form = AMDMSM_OUT_JACOBIAN;
+    hipStream_t st = o.stream ? (hipStream_t)o.stream : ctx->stream;
+    for (size_t k = 0; k < parts; ++k) {
+        const size_t lo = k * one, cnt = (k == parts - 1) ? n - lo : one;
+        rc = msm_device_impl(ctx, vt, (const uint32_t *)((const char *)d_bases + lo * aff_bytes),
+                             (const uint32_t *)((const char *)d_scalars + lo * fr_bytes), cnt,
+                             (uint32_t *)((char *)ctx->chunk_partials + k * xyz_bytes), &o);
+        if (rc) return rc;
+    }
+    vt->sum_points(st, (const uint32_t *)ctx->chunk_partials, (int)parts, form, d_out);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(st));   // the partials buffer is shared by the context
+    return AMDMSM_OK;
+}
+
 }  // namespace
 
 const group_vtable *amdmsm_internal_find_vt(int curve, int group) { return find_vt(curve, group); }
 void *amdmsm_internal_stream(amdmsm_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
 extern "C" {
+
+int amdmsm_abi_version(void) { return AMDMSM_ABI_VERSION; }
 
 int amdmsm_device_count(void) {
     int n = 0;
@@ -663,7 +737,7 @@ int amdmsm_plan_ex(int curve, int group, size_t n, int window_bits, int endomorp
                    uint32_t *num_buckets, size_t *workspace_bytes, int *endomorphism_used) {
     const group_vtable *vt = find_vt(curve, group);
     if (!vt) return AMDMSM_ERR_UNSUPPORTED;
-    amdmsm_opts o = {};
+    amdmsm_opts o = AMDMSM_OPTS_INIT;
     o.window_bits = window_bits;
     o.endomorphism = endomorphism;
     const bool glv = use_endomorphism(vt, n, &o, 0);
@@ -716,20 +790,26 @@ int amdmsm_get_timings_by_ticket(amdmsm_ctx *ctx, long long ticket, float ms[AMD
 
 int amdmsm_get_slot_timings(amdmsm_ctx *ctx, int slot, float ms[AMDMSM_MAX_PHASES]) {
     if (!ctx || !ms || slot < 0 || slot >= MAX_SLOTS) return AMDMSM_ERR_BAD_ARG;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     ws_slot &sl = ctx->slots[slot];
     if (!sl.ev_valid) return fail(ctx, AMDMSM_ERR_BAD_ARG, "no timed amdmsm_msm_device call recorded in this slot");
     return amdmsm_get_timings_by_ticket(ctx, sl.last_ticket, ms);
 }
 
 long long amdmsm_last_timing_ticket(amdmsm_ctx *ctx) {
-    if (!ctx || !ctx->timing || ctx->ticket == 0) return -1;
+    if (!ctx) return -1;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    if (!ctx->timing || ctx->ticket == 0) return -1;
     return (long long)(ctx->ticket - 1);
 }
 
 int amdmsm_get_timings_by_ticket(amdmsm_ctx *ctx, long long ticket, float ms[AMDMSM_MAX_PHASES]) {
     if (!ctx || !ms || ticket < 0) return AMDMSM_ERR_BAD_ARG;
+    // under the context lock: no MSM of another thread re-records ring events meanwhile.  The slot of
+    // ticket (next - TIMING_RING) is the one the next (or a failed) call records into: not readable.
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     for (int i = 0; i < AMDMSM_MAX_PHASES; ++i) ms[i] = 0.f;
-    if ((uint64_t)ticket >= ctx->ticket || ctx->ticket - (uint64_t)ticket > TIMING_RING)
+    if ((uint64_t)ticket >= ctx->ticket || ctx->ticket - (uint64_t)ticket >= TIMING_RING)
         return fail(ctx, AMDMSM_ERR_BAD_ARG, "timing ticket is not (or no longer) held");
     hipEvent_t *ev = ctx->ring[(uint64_t)ticket % TIMING_RING];
     dev_guard g(ctx->device);
@@ -741,6 +821,7 @@ int amdmsm_get_timings_by_ticket(amdmsm_ctx *ctx, long long ticket, float ms[AMD
 
 int amdmsm_get_timings(amdmsm_ctx *ctx, float ms[AMDMSM_MAX_PHASES]) {
     if (!ctx) return AMDMSM_ERR_BAD_ARG;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     return amdmsm_get_slot_timings(ctx, ctx->last_slot, ms);
 }
 
@@ -754,9 +835,10 @@ int amdmsm_get_timings(amdmsm_ctx *ctx, float ms[AMDMSM_MAX_PHASES]) {
 int amdmsm_msm_device(amdmsm_ctx *ctx, int curve, int group, const void *d_bases_affine, const void *d_scalars,
                       size_t n, void *d_out_xyz, const amdmsm_opts *opts) {
     GET_VT(ctx, curve, group);
+    CHECK_OPTS(ctx, opts);
     if (!d_out_xyz || (n && (!d_bases_affine || !d_scalars))) return fail(ctx, AMDMSM_ERR_BAD_ARG, "null pointer");
-    return msm_device_impl(ctx, vt, (const uint32_t *)d_bases_affine, (const uint32_t *)d_scalars, n,
-                           (uint32_t *)d_out_xyz, opts);
+    return msm_device_ranges(ctx, vt, (const uint32_t *)d_bases_affine, (const uint32_t *)d_scalars, n,
+                             (uint32_t *)d_out_xyz, opts);
 }
 
 size_t amdmsm_precompute_num_digits(int curve, size_t c) {
@@ -792,12 +874,13 @@ int amdmsm_precompute_bases_device(amdmsm_ctx *ctx, int curve, int group, const 
 int amdmsm_msm_precomputed_device(amdmsm_ctx *ctx, int curve, int group, const void *d_table, const void *d_scalars,
                                   size_t n, size_t c, size_t num_digits, void *d_out_xyz, const amdmsm_opts *opts) {
     GET_VT(ctx, curve, group);
+    CHECK_OPTS(ctx, opts);
     if (!d_out_xyz || (n && (!d_table || !d_scalars))) return fail(ctx, AMDMSM_ERR_BAD_ARG, "null pointer");
     if (c < 2 || c > 22 || num_digits < 1 || num_digits > 512) return fail(ctx, AMDMSM_ERR_BAD_ARG, "c / num_digits");
     // more digits than the scalar has windows (+1 for the final carry) would only index multiples
     // that are never selected; such a table layout is a caller error
     if (num_digits > ((size_t)vt->fr_bits + c - 1) / c + 1) return fail(ctx, AMDMSM_ERR_BAD_ARG, "num_digits exceeds ceil(bits/c) + 1");
-    amdmsm_opts o = {};
+    amdmsm_opts o = AMDMSM_OPTS_INIT;
     if (opts) o = *opts;
     else o.out_form = AMDMSM_OUT_LIBFF;
     o.window_bits = (int)c;
@@ -811,11 +894,13 @@ int amdmsm_msm_precomputed_device(amdmsm_ctx *ctx, int curve, int group, const v
         return msm_device_impl(ctx, vt, (const uint32_t *)d_table, (const uint32_t *)d_scalars, n, (uint32_t *)d_out_xyz,
                                &o, (int)num_digits);
     }
-    constexpr size_t MAX_PARTS = 64;
     const size_t parts = (n + max_pts - 1) / max_pts;
-    if (parts > MAX_PARTS) return fail(ctx, AMDMSM_ERR_TOO_LARGE, "input too large for one call");
+    if (parts > MAX_RANGES) return fail(ctx, AMDMSM_ERR_TOO_LARGE, "input too large for one call");
     const size_t xyz_bytes = (size_t)vt->el_words * 12, aff_bytes = (size_t)vt->el_words * 8;
-    if (!ctx->chunk_partials) HIP_TRY(ctx, hipMalloc(&ctx->chunk_partials, MAX_PARTS * 3 * 24 * 2 * 4));
+    {
+        const int rcp = ensure_partials(ctx);
+        if (rcp) return rcp;
+    }
     const int form = o.out_form;
     o.out_form = AMDMSM_OUT_JACOBIAN;
     hipStream_t st = o.stream ? (hipStream_t)o.stream : ctx->stream;
@@ -1027,6 +1112,7 @@ int register_bases_impl(amdmsm_ctx *ctx, const group_vtable *vt, const void *bas
     e.n = n;
     e.stride = stride;
     e.automatic = automatic;
+    e.aff_bytes = aff_bytes;
     HIP_TRY(ctx, hipMalloc(&e.d_aff, std::max<size_t>(n * aff_bytes, 256)));
     int rc = ensure_buf(ctx, ctx->hb_src, n * stride);
     if (rc == AMDMSM_OK) {
@@ -1066,7 +1152,8 @@ void drop_entry(amdmsm_ctx *ctx, size_t i) {
 }
 
 void *auto_cache_bases(amdmsm_ctx *ctx, const group_vtable *vt, const void *bases, size_t stride, int form, size_t n) {
-    const size_t cap = auto_cache_cap_bytes(), need = n * (size_t)vt->el_words * 8;
+    // (an entry is charged twice its affine bytes: the phi(P) records a split MSM attaches later count too)
+    const size_t cap = auto_cache_cap_bytes(), need = 2 * n * (size_t)vt->el_words * 8;
     if (!cap || need > cap || n < 1024) return nullptr;
     (void)hipStreamSynchronize(ctx->stream);
     for (;;) {
@@ -1074,7 +1161,7 @@ void *auto_cache_bases(amdmsm_ctx *ctx, const group_vtable *vt, const void *base
         for (size_t i = 0; i < ctx->bases.size(); ++i) {
             const base_entry &e = ctx->bases[i];
             if (!e.automatic) continue;
-            used += e.n * (size_t)vt->el_words * 8;
+            used += 2 * e.n * e.aff_bytes;
             if (lru == (size_t)-1 || e.last_use < ctx->bases[lru].last_use) lru = i;
         }
         if (used + need <= cap || lru == (size_t)-1) break;
@@ -1108,7 +1195,7 @@ int upload_bases_hook(void *arg, hipEvent_t *wait_for) {
 // ctx->hb_out (and the scalar statistics in ctx->hb_stats) -- the caller copies it back.
 // Device buffers are the context's grow-only staging buffers: no allocation in steady state.
 int host_msm_enqueue(amdmsm_ctx *ctx, const group_vtable *vt, const void *bases_xyz, size_t stride, int base_form,
-                     const void *scalars, size_t n, const amdmsm_opts *opts, bool want_stats) {
+                     const void *scalars, size_t n, const amdmsm_opts *opts, bool want_stats, bool clear_stats = true) {
     const size_t xyz_bytes = (size_t)vt->el_words * 12, aff_bytes = (size_t)vt->el_words * 8;
     const size_t fr_bytes = (size_t)vt->fr_words * 4;
     hipStream_t st = ctx->stream;
@@ -1117,9 +1204,9 @@ int host_msm_enqueue(amdmsm_ctx *ctx, const group_vtable *vt, const void *bases_
     if (want_stats) {
         rc = ensure_buf(ctx, ctx->hb_stats, 16);
         if (rc) return rc;
-        HIP_TRY(ctx, hipMemsetAsync(ctx->hb_stats.p, 0, 16, st));
+        if (clear_stats) HIP_TRY(ctx, hipMemsetAsync(ctx->hb_stats.p, 0, 16, st));
     }
-    amdmsm_opts o = {};
+    amdmsm_opts o = AMDMSM_OPTS_INIT;
     if (opts) o = *opts;
     else o.out_form = AMDMSM_OUT_LIBFF;
     o.stream = st;
@@ -1171,9 +1258,47 @@ int host_msm_enqueue(amdmsm_ctx *ctx, const group_vtable *vt, const void *bases_
 }
 
 // one partial point from the device that produced it to the combining device (xGMI peer copy)
+// (AMDMSM_FORCE_PEER_COPY=1: the peer-copy call also between two contexts of ONE device, so that a
+// one-GPU test box executes the exchange branch of the multi-device entries)
 hipError_t copy_partial(hipStream_t st, void *dst, int dst_dev, const void *src, int src_dev, size_t bytes) {
-    if (dst_dev == src_dev) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st);
+    static const bool force_peer = getenv("AMDMSM_FORCE_PEER_COPY") && atoi(getenv("AMDMSM_FORCE_PEER_COPY")) != 0;
+    if (dst_dev == src_dev && !force_peer) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st);
     return hipMemcpyPeerAsync(dst, dst_dev, src, src_dev, bytes, st);
+}
+
+// host_msm_enqueue for inputs of any length: above max_range_points() the reference's chunk loop
+// (multiexp.tcc:655-687), range after range through the same staging buffers (each range is
+// finished before the next one reuses them), the partial points summed at the end.  The result is
+// left in ctx->hb_out in the requested form, the 0 / 1 counters of all ranges in ctx->hb_stats.
+int host_msm_ranges(amdmsm_ctx *ctx, const group_vtable *vt, const void *bases_xyz, size_t stride, int base_form,
+                    const void *scalars, size_t n, const amdmsm_opts *opts, bool want_stats) {
+    const size_t maxr = max_range_points();
+    if (n <= maxr) return host_msm_enqueue(ctx, vt, bases_xyz, stride, base_form, scalars, n, opts, want_stats);
+    const size_t parts = (n + maxr - 1) / maxr;
+    if (parts > MAX_RANGES) return fail(ctx, AMDMSM_ERR_TOO_LARGE, "input too large for one call");
+    const size_t one = n / parts;
+    const size_t xyz_bytes = (size_t)vt->el_words * 12, fr_bytes = (size_t)vt->fr_words * 4;
+    int rc = ensure_partials(ctx);
+    if (rc) return rc;
+    amdmsm_opts o = AMDMSM_OPTS_INIT;
+    if (opts) o = *opts;
+    else o.out_form = AMDMSM_OUT_LIBFF;
+    const int form = o.out_form;
+    o.out_form = AMDMSM_OUT_JACOBIAN;
+    hipStream_t st = ctx->stream;
+    for (size_t k = 0; k < parts; ++k) {
+        const size_t lo = k * one, cnt = (k == parts - 1) ? n - lo : one;
+        rc = host_msm_enqueue(ctx, vt, (const char *)bases_xyz + lo * stride, stride, base_form,
+                              (const char *)scalars + lo * fr_bytes, cnt, &o, want_stats, k == 0);
+        if (rc) return rc;
+        HIP_TRY(ctx, hipMemcpyAsync((char *)ctx->chunk_partials + k * xyz_bytes, ctx->hb_out.p, xyz_bytes,
+                                    hipMemcpyDeviceToDevice, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_stream));
+    }
+    vt->sum_points(st, (const uint32_t *)ctx->chunk_partials, (int)parts, form, (uint32_t *)ctx->hb_out.p);
+    HIP_TRY(ctx, hipGetLastError());
+    return AMDMSM_OK;
 }
 
 int check_host_args(amdmsm_ctx *ctx, const group_vtable *vt, const void *bases_xyz, size_t &stride, const void *scalars,
@@ -1189,7 +1314,7 @@ int host_multi_exp(amdmsm_ctx *ctx, const group_vtable *vt, const void *bases_xy
                    const void *scalars, size_t n, void *out_xyz, const amdmsm_opts *opts, size_t stats[3]) {
     int rc = check_host_args(ctx, vt, bases_xyz, stride, scalars, n, out_xyz);
     if (rc) return rc;
-    rc = host_msm_enqueue(ctx, vt, bases_xyz, stride, base_form, scalars, n, opts, stats != nullptr);
+    rc = host_msm_ranges(ctx, vt, bases_xyz, stride, base_form, scalars, n, opts, stats != nullptr);
     if (rc) {
         (void)hipDeviceSynchronize();   // nothing of this call may still touch the staging buffers
         return rc;
@@ -1215,6 +1340,7 @@ extern "C" {
 int amdmsm_multi_exp(amdmsm_ctx *ctx, int curve, int group, const void *bases_xyz, size_t base_stride_bytes,
                      int base_form, const void *scalars, size_t n, void *out_xyz, const amdmsm_opts *opts) {
     GET_VT(ctx, curve, group);
+    CHECK_OPTS(ctx, opts);
     return host_multi_exp(ctx, vt, bases_xyz, base_stride_bytes, base_form, scalars, n, out_xyz, opts, nullptr);
 }
 
@@ -1227,6 +1353,7 @@ int amdmsm_multi_exp_filter_one_zero(amdmsm_ctx *ctx, int curve, int group, cons
     // only the three statistics the reference prints need the classification, which
     // k_scalar_stats counts on the device from the scalars already in HBM.
     GET_VT(ctx, curve, group);
+    CHECK_OPTS(ctx, opts);
     return host_multi_exp(ctx, vt, bases_xyz, base_stride_bytes, base_form, scalars, n, out_xyz, opts, stats);
 }
 
@@ -1276,9 +1403,9 @@ int amdmsm_invalidate_bases(amdmsm_ctx *ctx, const void *host_ptr, size_t bytes)
 // context k takes the contiguous range [k*one, (k+1)*one) (the last one the remainder), every
 // range runs the whole single-GPU pipeline on its own device from its own host thread, the
 // partial points are brought to the first device (hipMemcpyPeerAsync over xGMI) and summed there.
-int amdmsm_multi_exp_multi(amdmsm_ctx *const *ctxs, int ndev, int curve, int group, const void *bases_xyz,
-                           size_t base_stride_bytes, int base_form, const void *scalars, size_t n, void *out_xyz,
-                           const amdmsm_opts *opts) {
+int amdmsm_multi_exp_filter_one_zero_multi(amdmsm_ctx *const *ctxs, int ndev, int curve, int group, const void *bases_xyz,
+                                           size_t base_stride_bytes, int base_form, const void *scalars, size_t n,
+                                           void *out_xyz, const amdmsm_opts *opts, size_t stats[3]) {
     if (!ctxs || ndev < 1 || ndev > 64) return AMDMSM_ERR_BAD_ARG;
     for (int k = 0; k < ndev; ++k) {
         if (!ctxs[k]) return AMDMSM_ERR_BAD_ARG;
@@ -1287,9 +1414,12 @@ int amdmsm_multi_exp_multi(amdmsm_ctx *const *ctxs, int ndev, int curve, int gro
         }
     }
     amdmsm_ctx *c0 = ctxs[0];
+    CHECK_OPTS(c0, opts);
     const group_vtable *vt = find_vt(curve, group);
     if (!vt) return fail(c0, AMDMSM_ERR_UNSUPPORTED, "unknown curve/group");
     if (ndev == 1 || n < (size_t)ndev) {
+        if (stats) return amdmsm_multi_exp_filter_one_zero(c0, curve, group, bases_xyz, base_stride_bytes, base_form, scalars,
+                                                           n, out_xyz, opts, stats);
         return amdmsm_multi_exp(c0, curve, group, bases_xyz, base_stride_bytes, base_form, scalars, n, out_xyz, opts);
     }
     // lock order = argument order; every caller passing the same list is deadlock-free
@@ -1300,7 +1430,7 @@ int amdmsm_multi_exp_multi(amdmsm_ctx *const *ctxs, int ndev, int curve, int gro
     if (rc) return rc;
     const size_t xyz_bytes = (size_t)vt->el_words * 12, fr_bytes = (size_t)vt->fr_words * 4;
     const size_t one = n / (size_t)ndev;
-    amdmsm_opts o = {};
+    amdmsm_opts o = AMDMSM_OPTS_INIT;
     if (opts) o = *opts;
     else o.out_form = AMDMSM_OUT_LIBFF;
     const int final_form = o.out_form;
@@ -1310,8 +1440,9 @@ int amdmsm_multi_exp_multi(amdmsm_ctx *const *ctxs, int ndev, int curve, int gro
         amdmsm_ctx *ctx = ctxs[k];
         dev_guard g(ctx->device);
         const size_t lo = (size_t)k * one, cnt = (k == ndev - 1) ? n - lo : one;
-        int r = host_msm_enqueue(ctx, vt, (const char *)bases_xyz + lo * stride, stride, base_form,
-                                 (const char *)scalars + lo * fr_bytes, cnt, &o, false);
+        // every device classifies the scalars of its own range (multiexp.tcc:713-733); the counts are added up below
+        int r = host_msm_ranges(ctx, vt, (const char *)bases_xyz + lo * stride, stride, base_form,
+                                (const char *)scalars + lo * fr_bytes, cnt, &o, stats != nullptr);
         if (r == AMDMSM_OK && hipEventRecord(ctx->host_done, ctx->stream) != hipSuccess) r = AMDMSM_ERR_HIP;
         rcs[(size_t)k] = r;
     };
@@ -1332,23 +1463,44 @@ int amdmsm_multi_exp_multi(amdmsm_ctx *const *ctxs, int ndev, int curve, int gro
         // amdmsm_last_error is asked of the first context: carry the failing range's message over
         return fail(c0, rcs[(size_t)failed], "range " + std::to_string(failed) + ": " + ctxs[failed]->err);
     }
-    if (!c0->chunk_partials) HIP_TRY(c0, hipMalloc(&c0->chunk_partials, 64 * 3 * 24 * 2 * 4));
+    rc = ensure_partials(c0);
+    if (rc) return rc;
     hipStream_t st = c0->stream;
     for (int k = 0; k < ndev; ++k) {
         HIP_TRY(c0, hipStreamWaitEvent(st, ctxs[k]->host_done, 0));
         HIP_TRY(c0, copy_partial(st, (char *)c0->chunk_partials + (size_t)k * xyz_bytes, c0->device, ctxs[k]->hb_out.p,
                                  ctxs[k]->device, xyz_bytes));
     }
+    // (device 0's own partial has been copied out of hb_out by the loop above, in stream order)
     vt->sum_points(st, (const uint32_t *)c0->chunk_partials, ndev, final_form, (uint32_t *)c0->hb_out.p);
     HIP_TRY(c0, hipGetLastError());
     HIP_TRY(c0, hipMemcpyAsync(out_xyz, c0->hb_out.p, xyz_bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(c0, hipStreamSynchronize(st));
+    size_t zeros = 0, ones = 0;
     for (int k = 0; k < ndev; ++k) {
         dev_guard g(ctxs[k]->device);
         HIP_TRY(c0, hipStreamSynchronize(ctxs[k]->copy_stream));
         HIP_TRY(c0, hipStreamSynchronize(ctxs[k]->stream));
+        if (stats) {
+            uint32_t hs[4] = {};
+            HIP_TRY(c0, hipMemcpy(hs, ctxs[k]->hb_stats.p, 16, hipMemcpyDeviceToHost));
+            zeros += hs[0];
+            ones += hs[1];
+        }
+    }
+    if (stats) {
+        stats[0] = zeros;
+        stats[1] = ones;
+        stats[2] = n - zeros - ones;
     }
     return AMDMSM_OK;
+}
+
+int amdmsm_multi_exp_multi(amdmsm_ctx *const *ctxs, int ndev, int curve, int group, const void *bases_xyz,
+                           size_t base_stride_bytes, int base_form, const void *scalars, size_t n, void *out_xyz,
+                           const amdmsm_opts *opts) {
+    return amdmsm_multi_exp_filter_one_zero_multi(ctxs, ndev, curve, group, bases_xyz, base_stride_bytes, base_form, scalars, n,
+                                                  out_xyz, opts, nullptr);
 }
 
 // Device-resident counterpart: context k holds its own range (compact affine bases + scalars)
@@ -1364,32 +1516,57 @@ int amdmsm_msm_device_multi(amdmsm_ctx *const *ctxs, int ndev, int curve, int gr
         }
     }
     amdmsm_ctx *c0 = ctxs[0];
+    CHECK_OPTS(c0, opts);
     const group_vtable *vt = find_vt(curve, group);
     if (!vt) return fail(c0, AMDMSM_ERR_UNSUPPORTED, "unknown curve/group");
     std::vector<std::unique_lock<std::recursive_mutex>> locks;
     for (int k = 0; k < ndev; ++k) locks.emplace_back(ctxs[k]->mu);
     const size_t xyz_bytes = (size_t)vt->el_words * 12;
-    amdmsm_opts o = {};
+    amdmsm_opts o = AMDMSM_OPTS_INIT;
     if (opts) o = *opts;
     else o.out_form = AMDMSM_OUT_LIBFF;
     const int final_form = o.out_form;
-    hipStream_t user_stream = (hipStream_t)o.stream;   // ordering on device 0 only
+    hipStream_t user_stream = (hipStream_t)o.stream;
     o.out_form = AMDMSM_OUT_JACOBIAN;
     o.stream = nullptr;
+    // The ranges run on the contexts' own streams.  Inputs the caller produced on opts->stream are
+    // ordered before them: every context stream waits for an event recorded on that stream now.
+    if (user_stream) {
+        dev_guard g(c0->device);
+        HIP_TRY(c0, hipEventRecord(c0->bases_ready, user_stream));
+    }
     // kernels are asynchronous: one host thread enqueues all devices
-    for (int k = 0; k < ndev; ++k) {
+    int rc = AMDMSM_OK, failed = -1;
+    for (int k = 0; k < ndev && rc == AMDMSM_OK; ++k) {
         amdmsm_ctx *ctx = ctxs[k];
         dev_guard g(ctx->device);
-        int rc = ensure_buf(ctx, ctx->hb_out, xyz_bytes);
-        if (rc) return rc;
-        if (counts[k] && (!d_bases_affine[k] || !d_scalars[k])) return fail(c0, AMDMSM_ERR_BAD_ARG, "null pointer");
-        rc = msm_device_impl(ctx, vt, (const uint32_t *)d_bases_affine[k], (const uint32_t *)d_scalars[k], counts[k],
-                             (uint32_t *)ctx->hb_out.p, &o);
-        if (rc) return rc;
-        HIP_TRY(ctx, hipEventRecord(ctx->host_done, ctx->stream));
+        failed = k;
+        rc = ensure_buf(ctx, ctx->hb_out, xyz_bytes);
+        if (rc) break;
+        if (counts[k] && (!d_bases_affine[k] || !d_scalars[k])) {
+            rc = fail(ctx, AMDMSM_ERR_BAD_ARG, "null pointer");
+            break;
+        }
+        if (user_stream && hipStreamWaitEvent(ctx->stream, c0->bases_ready, 0) != hipSuccess) {
+            rc = fail(ctx, AMDMSM_ERR_HIP, "hipStreamWaitEvent");
+            break;
+        }
+        rc = msm_device_ranges(ctx, vt, (const uint32_t *)d_bases_affine[k], (const uint32_t *)d_scalars[k], counts[k],
+                               (uint32_t *)ctx->hb_out.p, &o);
+        if (rc) break;
+        if (hipEventRecord(ctx->host_done, ctx->stream) != hipSuccess) rc = fail(ctx, AMDMSM_ERR_HIP, "hipEventRecord");
+    }
+    if (rc) {
+        // nothing of this call may still be in flight when the caller reads the error
+        for (int k = 0; k < ndev; ++k) {
+            dev_guard g(ctxs[k]->device);
+            (void)hipDeviceSynchronize();
+        }
+        return fail(c0, rc, "range " + std::to_string(failed) + ": " + ctxs[failed]->err);
     }
     dev_guard g0(c0->device);
-    if (!c0->chunk_partials) HIP_TRY(c0, hipMalloc(&c0->chunk_partials, 64 * 3 * 24 * 2 * 4));
+    rc = ensure_partials(c0);
+    if (rc) return rc;
     hipStream_t st = user_stream ? user_stream : c0->stream;
     for (int k = 0; k < ndev; ++k) {
         HIP_TRY(c0, hipStreamWaitEvent(st, ctxs[k]->host_done, 0));
@@ -1420,6 +1597,7 @@ int stream_impl(amdmsm_ctx *ctx, int curve, int group, amdmsm_read_fn read, void
                 size_t n, size_t chunk_points, void *out_xyz, const amdmsm_opts *opts, size_t recs,
                 size_t precompute_c, bool compressed = false) {
     if (!ctx || !read || !out_xyz || (n && !scalars)) return AMDMSM_ERR_BAD_ARG;
+    CHECK_OPTS(ctx, opts);
     const group_vtable *vt = find_vt(curve, group);
     if (!vt) return fail(ctx, AMDMSM_ERR_UNSUPPORTED, "unknown curve/group");
     const size_t xyz_bytes = (size_t)vt->el_words * 12, aff_bytes = (size_t)vt->el_words * 8 * recs;
@@ -1473,7 +1651,7 @@ int stream_impl(amdmsm_ctx *ctx, int curve, int group, amdmsm_read_fn read, void
         TRY_S(hipMalloc(&d_sc[b], chunk_points * fr_bytes));
         TRY_S(hipStreamCreateWithFlags(&streams[b], hipStreamNonBlocking));
     }
-    amdmsm_opts o = {};
+    amdmsm_opts o = AMDMSM_OPTS_INIT;
     if (opts) o = *opts;
     const int final_form = opts ? opts->out_form : AMDMSM_OUT_LIBFF;
     o.out_form = AMDMSM_OUT_JACOBIAN;

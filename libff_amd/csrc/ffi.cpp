@@ -77,7 +77,7 @@ bool ffi_multiexp(int curve, int group, const void *bases, size_t bases_size, co
     }
     // The MSM is enqueued behind the validation without waiting for its verdict (one
     // synchronisation per call); a rejected input costs a wasted MSM, an accepted one nothing.
-    amdmsm_opts o = {};
+    amdmsm_opts o = AMDMSM_OPTS_INIT;
     o.out_form = AMDMSM_OUT_AFFINE;
     o.scalars_plain = 1;
     o.stream = st;
@@ -97,9 +97,61 @@ bool ffi_multiexp(int curve, int group, const void *bases, size_t bases_size, co
     return true;
 }
 
+#ifndef AMDMSM_FFI_NO_REFERENCE_SYMBOLS
+// The reference's own FFI entries (ffi/ffi.h:19-38, 61-80; ffi.cpp:16-54), device-backed, so that an
+// FFI host can load this one library: <curve>_init, <curve>_g1_add, <curve>_g1_mul.  Same reads as
+// the reference -- group_element_read / field_element_read (ffi_serialization.tcc:56-104, 150-171):
+// exact sizes, integers below their modulus, is_well_formed(), is_in_safe_subgroup() -- and the same
+// group_element_write of the affine result; false and an untouched output on any failure.
+// Both are MSMs of one and two points (s * p; 1 * a + 1 * b): the engine's addition ladder handles
+// a == b, a == -b and zero operands as libff's operator+ does (bls12_377_g1.cpp:121-178).
+bool ffi_init() {
+    std::lock_guard<std::mutex> lock(g_mu);
+    return ffi_ctx_locked() != nullptr;
+}
+
+bool ffi_g1_mul(int curve, const void *p, size_t p_size, const void *s, size_t s_size, void *out, size_t out_size) {
+    const group_vtable *vt = amdmsm_internal_find_vt(curve, AMDMSM_G1);
+    if (!vt || !p || !s) return false;
+    if (p_size != (size_t)vt->el_words * 8 || s_size != (size_t)vt->fr_words * 4) return false;
+    return ffi_multiexp(curve, AMDMSM_G1, p, p_size, s, s_size, out, out_size);
+}
+
+bool ffi_g1_add(int curve, const void *a, size_t a_size, const void *b, size_t b_size, void *out, size_t out_size) {
+    const group_vtable *vt = amdmsm_internal_find_vt(curve, AMDMSM_G1);
+    if (!vt || !a || !b) return false;
+    const size_t pt = (size_t)vt->el_words * 8, fr = (size_t)vt->fr_words * 4;
+    if (a_size != pt || b_size != pt) return false;
+    unsigned char bases[2 * 192], ones[2 * 48] = {};
+    if (pt > 192 || fr > 48) return false;
+    memcpy(bases, a, pt);
+    memcpy(bases + pt, b, pt);
+    ones[fr - 1] = 1;       // Fr 1, big-endian plain
+    ones[2 * fr - 1] = 1;
+    return ffi_multiexp(curve, AMDMSM_G1, bases, 2 * pt, ones, 2 * fr, out, out_size);
+}
+#endif
+
 }  // namespace
 
 extern "C" {
+
+#ifndef AMDMSM_FFI_NO_REFERENCE_SYMBOLS
+bool bls12_377_init() { return ffi_init(); }
+bool bls12_377_g1_add(const void *a_g1, size_t a_g1_size, const void *b_g1, size_t b_g1_size, void *out_g1, size_t out_g1_size) {
+    return ffi_g1_add(AMDMSM_CURVE_BLS12_377, a_g1, a_g1_size, b_g1, b_g1_size, out_g1, out_g1_size);
+}
+bool bls12_377_g1_mul(const void *p_g1, size_t p_g1_size, const void *s_fr, size_t s_fr_size, void *out_g1, size_t out_g1_size) {
+    return ffi_g1_mul(AMDMSM_CURVE_BLS12_377, p_g1, p_g1_size, s_fr, s_fr_size, out_g1, out_g1_size);
+}
+bool bw6_761_init() { return ffi_init(); }
+bool bw6_761_g1_add(const void *a_g1, size_t a_g1_size, const void *b_g1, size_t b_g1_size, void *out_g1, size_t out_g1_size) {
+    return ffi_g1_add(AMDMSM_CURVE_BW6_761, a_g1, a_g1_size, b_g1, b_g1_size, out_g1, out_g1_size);
+}
+bool bw6_761_g1_mul(const void *p_g1, size_t p_g1_size, const void *s_fr, size_t s_fr_size, void *out_g1, size_t out_g1_size) {
+    return ffi_g1_mul(AMDMSM_CURVE_BW6_761, p_g1, p_g1_size, s_fr, s_fr_size, out_g1, out_g1_size);
+}
+#endif
 
 bool amdmsm_ffi_set_device(int device) {
     std::lock_guard<std::mutex> lock(g_mu);

@@ -58,7 +58,10 @@ class ShardedMsm:
     step overlaps the bulk kernels of the next -- the way a prover issues its back-to-back MSMs.
     """
 
-    def __init__(self, engine, curve, group_id, process_group=None, depth=1):
+    def __init__(self, engine, curve, group_id, process_group=None, depth=1, force_exchange=False):
+        """force_exchange: run the exchange step (all-gather of the partial point on the device tensor +
+        k_sum_points) even at world size 1, where it is otherwise skipped -- so that a one-GPU box
+        executes the RCCL call and the combining kernel of the multi-rank path."""
         import torch
 
         self.torch = torch
@@ -67,6 +70,7 @@ class ShardedMsm:
         self.group_id = group_id
         self.pg = process_group
         self.depth = depth
+        self.force_exchange = force_exchange
         from .engine import sizes
 
         self.sz = sizes(curve, group_id)
@@ -99,7 +103,7 @@ class ShardedMsm:
         partial, result = self.partial[i], self.result[i]
         # inputs were produced on the caller's current stream
         stream.wait_stream(torch.cuda.current_stream(stream.device))
-        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.pg) > 1
+        multi = dist.is_available() and dist.is_initialized() and (dist.get_world_size(self.pg) > 1 or self.force_exchange)
         with torch.cuda.stream(stream):
             if not multi:
                 # one rank: the MSM writes the requested form itself, nothing to exchange or sum
@@ -115,6 +119,17 @@ class ShardedMsm:
             self.engine.sum_points_device(self.curve, self.group_id, stacked.data_ptr(), stacked.shape[0], out_form,
                                           result.data_ptr(), stream=stream.cuda_stream)
         return result, slot
+
+    def exchange_only(self, out_form):
+        """The exchange step alone on slot 0's buffers (all-gather of the current partial + local sum):
+        what bench.py times to split a sharded step into shard time and exchange latency."""
+        torch = self.torch
+        stream = self.streams[0]
+        with torch.cuda.stream(stream):
+            stacked = all_gather_partials(self.partial[0], group=self.pg).contiguous()
+            self.engine.sum_points_device(self.curve, self.group_id, stacked.data_ptr(), stacked.shape[0], out_form,
+                                          self.result[0].data_ptr(), stream=stream.cuda_stream)
+        return self.result[0]
 
     def synchronize(self):
         for s in self.streams:

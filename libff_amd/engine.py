@@ -34,16 +34,17 @@ multi_exp_method_BDLO12_signed = 4
 multi_exp_base_form_normal = 0
 multi_exp_base_form_special = 1
 
+ABI_VERSION = 3   # AMDMSM_ABI_VERSION of include/amdmsm.h this file mirrors (amdmsm_opts layout)
 OUT_JACOBIAN, OUT_LIBFF, OUT_AFFINE = 0, 1, 2
 PH_COUNT, PH_SCATTER, PH_ACCUM, PH_REDUCE, PH_FINAL, PH_TOTAL = range(6)
 MAX_PHASES = 8
 
 EXPORTED_SYMBOLS = [
-    "amdmsm_device_count", "amdmsm_ctx_create", "amdmsm_ctx_destroy", "amdmsm_strerror",
+    "amdmsm_abi_version", "amdmsm_device_count", "amdmsm_ctx_create", "amdmsm_ctx_destroy", "amdmsm_strerror",
     "amdmsm_last_error", "amdmsm_sizes", "amdmsm_plan", "amdmsm_plan_ex", "amdmsm_endomorphism_info",
     "amdmsm_endomorphism_digits_device", "amdmsm_pippenger_optimal_c",
     "amdmsm_bdlo12_signed_optimal_c", "amdmsm_multi_exp", "amdmsm_multi_exp_filter_one_zero",
-    "amdmsm_multi_exp_multi", "amdmsm_msm_device_multi", "amdmsm_register_bases", "amdmsm_unregister_bases",
+    "amdmsm_multi_exp_multi", "amdmsm_multi_exp_filter_one_zero_multi", "amdmsm_msm_device_multi", "amdmsm_register_bases", "amdmsm_unregister_bases",
     "amdmsm_invalidate_bases",
     "amdmsm_batch_to_special", "amdmsm_batch_exp", "amdmsm_multi_exp_stream", "amdmsm_multi_exp_stream_file",
     "amdmsm_multi_exp_stream_compressed", "amdmsm_multi_exp_stream_compressed_file", "amdmsm_disk_decode_device",
@@ -64,8 +65,10 @@ class AmdMsmError(RuntimeError):
 
 
 class _Opts(ctypes.Structure):
-    _fields_ = [("window_bits", ctypes.c_int), ("segment_len", ctypes.c_int), ("out_form", ctypes.c_int),
-                ("scalars_plain", ctypes.c_int), ("stream", ctypes.c_void_p), ("endomorphism", ctypes.c_int)]
+    # include/amdmsm.h amdmsm_opts, AMDMSM_ABI_VERSION 3 (struct_size first)
+    _fields_ = [("struct_size", ctypes.c_uint32), ("window_bits", ctypes.c_int), ("segment_len", ctypes.c_int),
+                ("out_form", ctypes.c_int), ("scalars_plain", ctypes.c_int), ("endomorphism", ctypes.c_int),
+                ("stream", ctypes.c_void_p)]
 
 
 _lib = None
@@ -80,6 +83,10 @@ def load_library():
                 f"{SO_PATH} is missing: build the HIP engine first (python -m libff_amd.build or "
                 "__graft_entry__.build()); libff_amd has no CPU implementation")
         L = ctypes.CDLL(SO_PATH)
+        if not hasattr(L, "amdmsm_abi_version") or L.amdmsm_abi_version() != ABI_VERSION:
+            raise AmdMsmError(f"{SO_PATH} was built from another include/amdmsm.h (ABI version "
+                              f"{L.amdmsm_abi_version() if hasattr(L, 'amdmsm_abi_version') else '< 3'}, this binding "
+                              f"expects {ABI_VERSION}): rebuild with python -m libff_amd.build")
         L.amdmsm_strerror.restype = ctypes.c_char_p
         L.amdmsm_last_error.restype = ctypes.c_char_p
         L.amdmsm_last_error.argtypes = [ctypes.c_void_p]
@@ -161,6 +168,27 @@ def multi_exp_multi(engines, curve, group, bases, scalars, base_form=multi_exp_b
     return out
 
 
+def multi_exp_filter_one_zero_multi(engines, curve, group, bases, scalars, base_form=multi_exp_base_form_normal,
+                                    out_form=OUT_AFFINE, window_bits=0, scalars_plain=False):
+    """amdmsm_multi_exp_filter_one_zero_multi: (result, {"skipped", "ones", "other"}) with the range split of
+    multi_exp_multi; every context counts the zeros / ones of its own range."""
+    bases = np.ascontiguousarray(bases, dtype=np.uint64)
+    scalars = np.ascontiguousarray(scalars, dtype=np.uint64)
+    s = sizes(curve, group)
+    n = bases.shape[0] if bases.ndim == 2 else 0
+    out = np.zeros(s["g_bytes"] // 8, dtype=np.uint64)
+    st = (ctypes.c_size_t * 3)()
+    e0 = engines[0]
+    ctxs = (ctypes.c_void_p * len(engines))(*[e.h for e in engines])
+    o = e0._opts(window_bits=window_bits, out_form=out_form, scalars_plain=scalars_plain)
+    rc = e0.lib.amdmsm_multi_exp_filter_one_zero_multi(ctxs, len(engines), curve, group, _np_ptr(bases) if n else None,
+                                                       ctypes.c_size_t(s["g_bytes"]), base_form,
+                                                       _np_ptr(scalars) if n else None, ctypes.c_size_t(n), _np_ptr(out),
+                                                       ctypes.byref(o), st)
+    e0._check(rc, "amdmsm_multi_exp_filter_one_zero_multi")
+    return out, {"skipped": st[0], "ones": st[1], "other": st[2]}
+
+
 def msm_device_multi(engines, curve, group, d_bases, d_scalars, counts, d_out_dev0, out_form=OUT_LIBFF, window_bits=0,
                      scalars_plain=False, stream=None):
     """amdmsm_msm_device_multi: range k (compact affine bases, scalars; device pointers on
@@ -218,7 +246,8 @@ class Engine:
     def _opts(self, window_bits=0, segment_len=0, out_form=OUT_LIBFF, scalars_plain=False, stream=None):
         # self.endomorphism: amdmsm_opts.endomorphism for every call of this engine (0 = only where the
         # whole curve group has order r, 1 = the bases are promised to lie in the order-r subgroup, -1 = off)
-        return _Opts(window_bits, segment_len, out_form, int(scalars_plain), stream, int(self.endomorphism))
+        return _Opts(ctypes.sizeof(_Opts), window_bits, segment_len, out_form, int(scalars_plain), int(self.endomorphism),
+                     stream)
 
     # ---------------------------------------------------------------- host API
     def multi_exp(self, curve, group, bases, scalars, method=multi_exp_method_BDLO12_signed,

@@ -34,6 +34,7 @@ SRCS=(
     "$REF"/libff/common/utils.cpp
     "$REF"/libff/common/double.cpp
     "$REF"/libff/algebra/serialization.cpp
+    "$REF"/ffi/ffi.cpp
 )
 FLAGS=(-std=c++11 -O2 -DNDEBUG -fopenmp -DMULTICORE=1 -DCURVE_ALT_BN128
        -DNO_PROCPS -DBINARY_OUTPUT -DMONTGOMERY_OUTPUT -DUSE_ASM
@@ -61,7 +62,7 @@ AMDSO="$HERE/../libff_amd/libamdmsm.so"
 if [ -f "$AMDSO" ]; then
     refobjs=()
     for o in "${objs[@]}"; do
-        case "$o" in *ref_shim.o) ;; *) refobjs+=("$o") ;; esac
+        case "$o" in *ref_shim.o|*ffi_ffi.o) ;; *) refobjs+=("$o") ;; esac
     done
     g++ "${FLAGS[@]}" -I"$HERE/../include" -c "$HERE/shim_check.cpp" -o "$OBJ/shim_check.o"
     g++ -fopenmp -o "$OUT/shim_check" "$OBJ/shim_check.o" "${refobjs[@]}" -L"$HERE/../libff_amd" -lamdmsm \

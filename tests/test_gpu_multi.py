@@ -139,6 +139,44 @@ def test_north_star_size_2p26_closed_form(engine, port):
         e2.close()
 
 
+def _tiled_pool_closed_form(port, curve, group, n, m, seed):
+    """scalars s_i = pool[i mod m], bases (i+1)G: sum_i s_i (i+1) G = (sum_j pool_j * sum_{i = j mod m} (i+1)) G,
+    m terms on the CPU (test_multiexp.cpp:205-256's pattern); returns (pool, expected affine point)."""
+    pool = port.scalars_sha512(curve, seed, m)
+    plain = port.fr_as_bigint(curve, pool)
+    r = to_int(golden()[f"{libff_amd.engine.CURVE_NAMES[curve]}_g1/fr_modulus"])
+    reps = n // m
+    k = 0
+    for j in range(m):
+        k += to_int(plain[j]) * (reps * (j + 1) + m * (reps * (reps - 1) // 2))
+    k %= r
+    fl = pool.shape[1]
+    k_mont = port.fr_from_bigint(curve, np.array([[(k >> (64 * j)) & 0xFFFFFFFFFFFFFFFF for j in range(fl)]], dtype=np.uint64))[0]
+    one, _ = port.group_consts(curve, group)
+    return pool, port.group_op(curve, group, 4, port.scalar_mul(curve, group, one, k_mont))
+
+
+@pytest.mark.parametrize("name,curve,group", [("bw6_761_g1", 2, 1), ("bls12_377_g2", 1, 2)])
+@pytest.mark.parametrize("endo", [0, 1])
+def test_config4_stated_totals_2p24_closed_form(port, name, curve, group, endo):
+    """BASELINE configs[4] at its stated total on one GPU: bw6_761 G1 and bls12_377 G2 MSMs over 2^24
+    points (3 GiB of affine bases each, generated in HBM), bit-exact against the closed form -- on the
+    default path and with the endomorphism split permitted (the bases are multiples of the generator),
+    which is how bench.py's configs[4] legs run."""
+    n, m = 1 << 24, 4096
+    pool, want = _tiled_pool_closed_form(port, curve, group, n, m, 2424 + group)
+    eng = libff_amd.Engine(0, endomorphism=endo)
+    sc = np.ascontiguousarray(np.tile(pool, (n // m, 1)))
+    res = _Resident(eng, curve, group, n, 0, sc)
+    del sc
+    try:
+        eng.msm_device(curve, group, res.d_bases.value, res.d_sc.value, n, res.d_out.value, out_form=libff_amd.OUT_AFFINE)
+        assert (res.result() == want).all()
+    finally:
+        res.free()
+        eng.close()
+
+
 def test_config4_two_msms_issued_together(engine, port):
     """configs[4] per-rank shard: bw6_761 G1 2^21 and bls12_377 G2 2^21 enqueued back to back on two
     contexts (two streams) with no synchronisation in between, as a BW6/BLS12 prover issues
@@ -279,7 +317,9 @@ def test_precomputed_rejects_unservable_num_digits(engine, port):
 def test_sharded_msm_nccl_world_size_one():
     """ShardedMsm (libff_amd/distributed.py, what bench.py --gpus N runs) through the nccl backend
     at world size 1, depth 1 and 2, with scalars that change every step: each result against the
-    oracle.  Child process: it initialises torch.distributed."""
+    oracle -- without and with force_exchange (the all-gather over RCCL on the device tensor and the
+    combining kernel executed even though there is one rank).  Child process: it initialises
+    torch.distributed."""
     import subprocess
 
     code = r'''
@@ -301,8 +341,9 @@ bases_h = port.bases_seq(curve, group, n, first=0)
 bases = torch.empty((n, sz["affine_bytes"] // 8), dtype=torch.int64, device=dev)
 eng.gen_bases_seq_device(curve, group, 0, n, bases.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
 torch.cuda.synchronize()
-for depth in (1, 2):
-    msm = ShardedMsm(eng, curve, group, depth=depth)
+for depth, force in ((1, False), (2, False), (1, True), (2, True)):
+    # force_exchange: the RCCL all-gather on the device tensor and k_sum_points really run at world size 1
+    msm = ShardedMsm(eng, curve, group, depth=depth, force_exchange=force)
     outs, wants = [], []
     for step in range(4):
         sc_h = port.scalars_sha512(curve, 1000 * step + depth, n)
@@ -405,3 +446,85 @@ def test_bench_multi_rank_path_rehearsal():
     assert set(legs) == {"same_total_on_one_gpu", "weak_2p20_per_gpu", "config4_bw6_761_g1_plus_bls12_377_g2"}
     assert all(v["value"] > 0 for v in legs.values())
     assert d["roofline"]["frac"] > 0 and "cpu_baseline" not in d
+    cfg = d["config"]
+    assert cfg["shard_ms"] > 0 and cfg["exchange_ms"] > 0 and abs(cfg["predicted_ms"] - cfg["shard_ms"] - cfg["exchange_ms"]) < 1e-9
+
+
+def test_range_split_peer_copy_and_filter_multi():
+    """Inputs longer than one MSM handles are cut into contiguous ranges whose partial results are summed
+    (the reference's chunk loop, multiexp.tcc:655-687) -- AMDMSM_MAX_RANGE_POINTS lowers the limit from
+    2^28 to 5000 points here so that every entry point takes that path: the device entry, the host entry
+    (with its 0 / 1 statistics accumulated over the ranges), the two multi-device entries.
+    AMDMSM_FORCE_PEER_COPY=1 makes the multi-device entries call hipMemcpyPeerAsync although both
+    contexts sit on the one GPU of the box.  Everything against the oracle.  Child process: both knobs
+    are read once per process."""
+    import subprocess
+
+    code = r'''
+import os, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np
+import libff_amd
+from oracle import port
+port.build()
+e1, e2 = libff_amd.Engine(0), libff_amd.Engine(0)
+for curve, group, n in ((0, 1, 20001), (1, 2, 12007)):
+    s = libff_amd.sizes(curve, group)
+    bases = port.bases_r32(curve, group, n) if curve else port.bases_seq(curve, group, n)
+    sc = port.scalars_sha512(curve, 77, n)
+    one = port.fr_from_bigint(curve, np.array([[1] + [0] * (sc.shape[1] - 1)], dtype=np.uint64))[0]
+    sc[5::7] = 0
+    sc[3::11] = one
+    zeros, ones = len(range(5, n, 7)), len([i for i in range(3, n, 11) if i %% 7 != 5])
+    want = port.multi_exp(curve, group, bases, sc, port.BDLO12_SIGNED, port.FORM_SPECIAL, chunks=8, omp=True)
+    # host entry, 5 / 3 ranges
+    got = e1.multi_exp(curve, group, bases, sc, base_form=libff_amd.multi_exp_base_form_special)
+    assert (got == want).all(), ("host", curve, group)
+    got, st = e1.multi_exp_filter_one_zero(curve, group, bases, sc, base_form=libff_amd.multi_exp_base_form_special)
+    assert (got == want).all() and (st["skipped"], st["ones"], st["other"]) == (zeros, ones, n - zeros - ones), st
+    # two contexts, each range split again; partials through hipMemcpyPeerAsync
+    got = libff_amd.multi_exp_multi([e1, e2], curve, group, bases, sc, base_form=libff_amd.multi_exp_base_form_special)
+    assert (got == want).all(), ("multi", curve, group)
+    got, st = libff_amd.multi_exp_filter_one_zero_multi([e1, e2], curve, group, bases, sc,
+                                                        base_form=libff_amd.multi_exp_base_form_special)
+    assert (got == want).all() and (st["skipped"], st["ones"], st["other"]) == (zeros, ones, n - zeros - ones), st
+    # device entry
+    aff = np.ascontiguousarray(bases[:, : s["affine_bytes"] // 8])
+    d_b, d_s, d_o = e1.malloc(aff.nbytes), e1.malloc(sc.nbytes), e1.malloc(s["g_bytes"])
+    e1.h2d(d_b, aff); e1.h2d(d_s, sc)
+    e1.msm_device(curve, group, d_b.value, d_s.value, n, d_o.value, out_form=libff_amd.OUT_AFFINE)
+    e1.synchronize()
+    out = np.zeros(s["g_bytes"] // 8, dtype=np.uint64)
+    e1.d2h(out, d_o)
+    assert (out == want).all(), ("device", curve, group)
+    half = n // 2 - 1
+    libff_amd.msm_device_multi([e1, e2], curve, group, [d_b.value, d_b.value + half * s["affine_bytes"]],
+                               [d_s.value, d_s.value + half * s["fr_bytes"]], [half, n - half], d_o.value,
+                               out_form=libff_amd.OUT_AFFINE)
+    e1.d2h(out, d_o)
+    assert (out == want).all(), ("device multi", curve, group)
+print("ranges-ok")
+''' % (REPO, os.path.join(REPO, "tests"))
+    env = dict(os.environ, AMDMSM_MAX_RANGE_POINTS="5000", AMDMSM_FORCE_PEER_COPY="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and "ranges-ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+def test_opts_struct_size_is_checked(engine):
+    """amdmsm_opts carries its own size (AMDMSM_ABI_VERSION 3): a caller compiled against another layout
+    is refused with AMDMSM_ERR_BAD_ARG instead of having its fields misread."""
+    import ctypes
+
+    from libff_amd.engine import _Opts
+
+    assert engine.lib.amdmsm_abi_version() == libff_amd.engine.ABI_VERSION
+    o = engine._opts()
+    o.struct_size = ctypes.sizeof(_Opts) - 8   # e.g. the 24-byte layout of the first ABI
+    out = np.zeros(12, dtype=np.uint64)
+    rc = engine.lib.amdmsm_multi_exp(engine.h, 0, 1, None, ctypes.c_size_t(0), 0, None, ctypes.c_size_t(0),
+                                     out.ctypes.data_as(ctypes.c_void_p), ctypes.byref(o))
+    assert rc == -2 and b"struct_size" in engine.lib.amdmsm_last_error(engine.h)
+    o.struct_size = ctypes.sizeof(_Opts)
+    rc = engine.lib.amdmsm_multi_exp(engine.h, 0, 1, None, ctypes.c_size_t(0), 0, None, ctypes.c_size_t(0),
+                                     out.ctypes.data_as(ctypes.c_void_p), ctypes.byref(o))
+    assert rc == 0

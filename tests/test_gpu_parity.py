@@ -382,6 +382,39 @@ def test_ffi_multiexp(engine, port, name, curve, group):
     assert (out == zero_enc).all()
 
 
+@pytest.mark.parametrize("cname,curve", [("bls12_377", 1), ("bw6_761", 2)])
+def test_ffi_reference_symbols(engine, cname, curve):
+    """<curve>_init / <curve>_g1_add / <curve>_g1_mul (ffi/ffi.h:19-38, 61-80), device-backed: every row of
+    tests/golden/ffi_ops.npz -- inputs and what the reference's own ffi.cpp returned for them, incl. P + P,
+    P + (-P), zero operands, scalars 0 / 1 / r - 1 / >= r, points off the curve and outside the safe subgroup
+    -- gives the same bool and, where true, the same bytes; a failed call leaves the output untouched."""
+    import ctypes
+
+    lib = engine.lib
+    f = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ffi_ops.npz")))
+    init, add, mul = (getattr(lib, f"{cname}_{x}") for x in ("init", "g1_add", "g1_mul"))
+    init.restype = add.restype = mul.restype = ctypes.c_bool
+    assert init()
+
+    def call(fn, a, b, o):
+        return bool(fn(a.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(a.size), b.ctypes.data_as(ctypes.c_void_p),
+                       ctypes.c_size_t(b.size), o.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(o.size)))
+
+    for fn, ka, kb, kind in ((add, "add_a", "add_b", "add"), (mul, "mul_p", "mul_s", "mul")):
+        A, B = f[f"{cname}/{ka}"], f[f"{cname}/{kb}"]
+        for k in range(A.shape[0]):
+            o = np.full(A.shape[1], 0xA5, dtype=np.uint8)
+            ok = call(fn, np.ascontiguousarray(A[k]), np.ascontiguousarray(B[k]), o)
+            assert ok == bool(f[f"{cname}/{kind}_ok"][k]), (kind, k)
+            assert (o == f[f"{cname}/{kind}_out"][k]).all(), (kind, k)   # rejected rows keep the 0xA5 fill
+        # exact sizes (object_read_from_buffer, ffi_serialization.tcc:98-104)
+        o = np.full(A.shape[1], 0xA5, dtype=np.uint8)
+        assert not call(fn, np.ascontiguousarray(A[0][:-1]), np.ascontiguousarray(B[0]), o)
+        assert not call(fn, np.ascontiguousarray(A[0]), np.ascontiguousarray(B[0][:-1]), o)
+        assert not call(fn, np.ascontiguousarray(A[0]), np.ascontiguousarray(B[0]), o[:-1])
+        assert (o == 0xA5).all()
+
+
 @pytest.mark.parametrize("name,curve,group", GROUPS)
 def test_batch_exp_fixed_base(engine, port, name, curve, group):
     """Fixed-base batch exponentiation: get_window_table + batch_exp /

@@ -1,6 +1,8 @@
 """Pin the C restatement (oracle/msm_oracle.c) against the committed golden fixtures
 (generated from the reference by tests/golden/make_golden.py) and against the literal
 known-answer vectors of the reference's own tests.  CPU only."""
+import os
+
 import numpy as np
 import pytest
 
@@ -267,3 +269,27 @@ def test_on_disk_base_records(port, name, curve, group):
     if f"{name}/disk_stream_msm" in g:
         sc = port.scalars_sha512(curve, 60, 6)
         assert (port.multi_exp(curve, group, elems, sc, port.BDLO12_SIGNED, 0) == g[f"{name}/disk_stream_msm"]).all()
+
+
+@pytest.mark.parametrize("cname,curve", [("bls12_377", 1), ("bw6_761", 2)])
+def test_ffi_add_mul_fixtures(port, cname, curve):
+    """tests/golden/ffi_ops.npz holds what the reference's own <curve>_g1_add / <curve>_g1_mul returned
+    (ffi.cpp:16-54 compiled in place; make_ffi_golden.py): the restatement's FFI codecs and group law
+    reproduce every accepted row byte for byte and reject every row the reference rejected."""
+    f = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ffi_ops.npz")))
+    for k in range(f[f"{cname}/add_ok"].shape[0]):
+        a = port.ffi_group_read(curve, 1, f[f"{cname}/add_a"][k])
+        b = port.ffi_group_read(curve, 1, f[f"{cname}/add_b"][k])
+        ok = a is not None and b is not None
+        assert ok == bool(f[f"{cname}/add_ok"][k]), k
+        if ok:
+            got = port.ffi_group_write(curve, 1, port.group_op(curve, 1, 5, a, b))
+            assert (got == f[f"{cname}/add_out"][k]).all(), k
+    for k in range(f[f"{cname}/mul_ok"].shape[0]):
+        p = port.ffi_group_read(curve, 1, f[f"{cname}/mul_p"][k])
+        s = port.ffi_fr_read(curve, f[f"{cname}/mul_s"][k])
+        ok = p is not None and s is not None
+        assert ok == bool(f[f"{cname}/mul_ok"][k]), k
+        if ok:
+            got = port.ffi_group_write(curve, 1, port.scalar_mul(curve, 1, p, s))
+            assert (got == f[f"{cname}/mul_out"][k]).all(), k
