@@ -142,6 +142,10 @@ struct plan_t {
     size_t off_counts = 0, off_lists = 0, off_buckets = 0, off_lvl0 = 0, off_lvl1 = 0, total = 0;
     size_t off_pfirst = 0, off_plast = 0, off_cont = 0, off_queue = 0;
     size_t off_coarse = 0, off_cursor = 0, off_tmp_payload = 0, off_tmp_key = 0, off_big = 0;
+    // bucket reduction as row / column sums + bit planes (vt->reduce_rowcol): scratch and serial lengths
+    bool rowcol = false;
+    uint32_t q_row = 0, q_col = 0;
+    size_t off_rc = 0, off_planes = 0, off_winsum = 0, rc_points = 0;
     size_t list_stride = 0;
     bool glv = false;        // endomorphism split: the sorted columns are 2 * n_real half-length scalars
     size_t off_endo = 0;     // phi(P) = (beta x, y) of every base, compact affine
@@ -333,6 +337,32 @@ int make_plan(const group_vtable *vt, size_t n, int c_req, int L_req, plan_t &p,
     off = align_up(off + (size_t)p.W * p.list_stride * 4, 256);   // 16-bit fine keys use half of it
     p.off_endo = off;
     if (glv) off = align_up(off + (n / 2) * (size_t)vt->el_words * 2 * 4, 256);
+    // Bucket reduction as plain sums (row / column sums of the weight matrix, bit planes, one short
+    // Horner per window) from c = 10 up; below that a window's few segments fold inside one wave of
+    // k_reduce_segments.  AMDMSM_ROWCOL=0 keeps the segment kernels everywhere (A/B runs).
+    // Lanes add q buckets serially before the butterfly: the smallest q (>= 4 / 4) that keeps the
+    // row and column lanes together within about two waves per SIMD -- measured: see make_plan's note
+    // in profiles/r03_experiments.txt.
+    {
+        static const int rc_env = getenv("AMDMSM_ROWCOL") ? atoi(getenv("AMDMSM_ROWCOL")) : 1;
+        static const int rc_min_c = getenv("AMDMSM_ROWCOL_MIN_C") ? atoi(getenv("AMDMSM_ROWCOL_MIN_C")) : 10;
+        static const int qr_env = getenv("AMDMSM_ROWCOL_QROW") ? atoi(getenv("AMDMSM_ROWCOL_QROW")) : 0;
+        static const int qc_env = getenv("AMDMSM_ROWCOL_QCOL") ? atoi(getenv("AMDMSM_ROWCOL_QCOL")) : 0;
+        p.rowcol = rc_env != 0 && p.c >= rc_min_c;
+        const int h = p.c / 2;
+        const size_t C = (size_t)1 << h, R = p.B >> h;
+        uint32_t q = 4;
+        while (q < 64 && (size_t)p.W * p.B * red_lanes * 2 / q > (size_t)140000) q <<= 1;
+        p.q_row = qr_env > 0 ? (uint32_t)qr_env : q;
+        p.q_col = qc_env > 0 ? (uint32_t)qc_env : q;
+        p.rc_points = R + 1 + C;
+        p.off_rc = off;
+        off = align_up(off + (size_t)p.W * p.rc_points * xyz_bytes, 256);
+        p.off_planes = off;
+        off = align_up(off + (size_t)p.W * p.c * xyz_bytes, 256);
+        p.off_winsum = off;
+        off = align_up(off + (size_t)p.W * xyz_bytes, 256);
+    }
     p.total = off;
     return AMDMSM_OK;
 }
@@ -538,19 +568,26 @@ int msm_device_impl(amdmsm_ctx *ctx, const group_vtable *vt, const uint32_t *d_b
                              pfirst + (size_t)w0 * p.T * zzw, plast + (size_t)w0 * p.T * zzw, cont + (size_t)w0 * p.T,
                              (uint32_t *)(ws + p.off_queue + g * p.queue_stride), wg, p.B, p.S, p.T);
         uint32_t *src = lvl0 + (size_t)w0 * M0 * xyzw, *dst = lvl1 + (size_t)w0 * cap1 * xyzw;
-        vt->reduce_segments(ts, buckets + (size_t)w0 * p.B * zzw, wg, p.B, p.L, src);
-        const uint32_t fold = (uint32_t)vt->reduce_fold;
-        uint32_t M = (uint32_t)M0;
-        M /= std::min<uint32_t>(M, fold);   // folded per wave inside reduce_segments
-        while (M > 1) {
-            if ((size_t)M * (64 / fold) <= 256) {   // the remaining levels in one launch
-                vt->sum_block(ts, src, wg, M, dst);
-                M = 1;
-            } else {
-                vt->sum_butterfly(ts, src, wg, M, dst);
-                M /= std::min<uint32_t>(M, fold);
+        if (p.rowcol) {
+            src = (uint32_t *)(ws + p.off_winsum) + (size_t)w0 * xyzw;
+            vt->reduce_rowcol(ts, buckets + (size_t)w0 * p.B * zzw, wg, p.B, p.c, p.q_row, p.q_col,
+                              (uint32_t *)(ws + p.off_rc) + (size_t)w0 * p.rc_points * xyzw,
+                              (uint32_t *)(ws + p.off_planes) + (size_t)w0 * p.c * xyzw, src);
+        } else {
+            vt->reduce_segments(ts, buckets + (size_t)w0 * p.B * zzw, wg, p.B, p.L, src);
+            const uint32_t fold = (uint32_t)vt->reduce_fold;
+            uint32_t M = (uint32_t)M0;
+            M /= std::min<uint32_t>(M, fold);   // folded per wave inside reduce_segments
+            while (M > 1) {
+                if ((size_t)M * (64 / fold) <= 256) {   // the remaining levels in one launch
+                    vt->sum_block(ts, src, wg, M, dst);
+                    M = 1;
+                } else {
+                    vt->sum_butterfly(ts, src, wg, M, dst);
+                    M /= std::min<uint32_t>(M, fold);
+                }
+                std::swap(src, dst);
             }
-            std::swap(src, dst);
         }
         // Horner over this group's windows, continuing from the groups above
         if (g > 0) HIP_TRY(ctx, hipStreamWaitEvent(ts, sl.tail_done[g - 1], 0));

@@ -131,6 +131,12 @@ struct group_vtable {
     void (*sum_butterfly)(hipStream_t, const uint32_t* in, int W, uint32_t M, uint32_t* out);
     // out[w] = sum_i in[w][i], i < M, one workgroup per window; M * (64 / reduce_fold) <= 256
     void (*sum_block)(hipStream_t, const uint32_t* in, int W, uint32_t M, uint32_t* out);
+    // The bucket reduction as plain sums (msm_group.hip k_bucket_sums / k_plane_sums / k_window_horner):
+    // out[w] = sum_b (b + 1) * bucket[w][b].  B = 2^(c-1); q_row / q_col: buckets a lane adds serially in
+    // the row / column sums (rounded to what the butterfly width admits); rc: W * (R + 1 + C) points and
+    // planes: W * c points of scratch, C = 2^ceil((c-1)/2), R = B / C
+    void (*reduce_rowcol)(hipStream_t, const uint32_t* buckets, int W, uint32_t B, int c, uint32_t q_row, uint32_t q_col,
+                          uint32_t* rc, uint32_t* planes, uint32_t* out);
     // Horner over window sums (high to low, c doublings between), write one point; init (engine
     // Jacobian, may be null) = value carried in from the windows above window_sums[W-1]
     void (*horner)(hipStream_t, const uint32_t* window_sums, int W, int c, int form, const uint32_t* init,

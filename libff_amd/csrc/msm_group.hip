@@ -1369,6 +1369,85 @@ __global__ void __launch_bounds__(SUMW_THREADS) k_sum_block_wide(const uint32_t*
     for (uint32_t t = threadIdx.x; t < (uint32_t)XYZW; t += SUMW_THREADS) out[w * XYZW + t] = buf[cur][t];
 }
 
+// ---- bucket reduction without per-segment multiples (the default from AMDMSM_ROWCOL_MIN_C up) ----
+// sum_b (b + 1) B_b (multiexp_accumulate_buckets, multiexp.tcc:90-125) = sum_k 2^k P_k with the bit planes
+// P_k = sum of the buckets whose weight b + 1 has bit k set.  The weights 1 .. B (B = 2^(c-1)) are laid
+// out as a matrix, b + 1 = hi * C + lo with C = 2^h columns (h = ceil((c-1)/2)) and rows hi = 0 .. R
+// (R = B / C; row R holds the single weight B):
+//   k_bucket_sums    row[hi] = sum_lo bucket(hi, lo) and col[lo] = sum_hi bucket(hi, lo): two plain
+//                    additions per bucket, q in the lane and a butterfly over the len / q lanes of a sum
+//   k_plane_sums     P_k from the C column sums (k < h: columns whose index has bit k) or the R + 1 row
+//                    sums (k >= h): one workgroup per (window, plane), at most max(C, R) / 2 inputs
+//   k_window_horner  sum_k 2^k P_k per window, one wave each on lane-split elements (horner_chain with
+//                    one doubling between planes)
+// Against k_reduce_segments this removes the (segment offset) x (segment sum) multiples -- 13 doublings
+// and up to 13 additions per lane at 2^20 points, two thirds of that kernel's field products -- and every
+// level is a plain sum.
+__global__ void __launch_bounds__(64) k_bucket_sums(const uint32_t* __restrict__ buckets, int W, uint32_t B, int h,
+                                                    uint32_t q_row, uint32_t q_col, uint32_t row_blocks,
+                                                    uint32_t* __restrict__ out) {
+    const bool col = blockIdx.x >= row_blocks;
+    const size_t t = ((size_t)(blockIdx.x - (col ? row_blocks : 0u)) * 64 + threadIdx.x) / RED_LANES;
+    const uint32_t C = 1u << h, R = B >> h;
+    const uint32_t q = col ? q_col : q_row, len = col ? R : C;
+    const uint32_t g = len / q;                      // lanes per sum, 1 .. RED_FOLD
+    const uint32_t nout = col ? C : R + 1;
+    const size_t per_w = (size_t)nout * g;
+    const size_t w = t / per_w;
+    const uint32_t rem = (uint32_t)(t % per_w), o = rem / g, j = rem % g;
+    const bool valid = w < (size_t)W;
+    Xyzz<ER> xa, xb;
+    xyzz_set_inf(xa);
+    if (valid) {
+        const uint32_t* bk = buckets + w * (size_t)B * ZZW;
+        for (uint32_t i = 0; i < q; ++i) {
+            const uint32_t idx = j * q + i;
+            const uint64_t b1 = col ? (uint64_t)idx * C + o : (uint64_t)o * C + idx;   // weight b + 1
+            if (b1 >= 1 && b1 <= B) {
+                load_xyzz(xb, bk + (size_t)(b1 - 1) * ZZW);
+                xyzz_add(xa, xa, xb);
+            }
+        }
+    }
+    Jac<ER> p;
+    xyzz_to_jac(p, xa);
+    wave_group_sum_r(p, g);
+    if (valid && j == 0) store_jac(out + (w * (size_t)(R + 1 + C) + (col ? R + 1 + o : o)) * XYZW, p);
+}
+
+// rc[w]: R + 1 row sums, then C column sums (k_bucket_sums); planes[w][k], k < c
+__global__ void __launch_bounds__(256) k_plane_sums(const uint32_t* __restrict__ rc, int W, int c, int h,
+                                                     uint32_t* __restrict__ planes) {
+    __shared__ uint32_t part[4 * XYZW];
+    const uint32_t w = blockIdx.x / (uint32_t)c, k = blockIdx.x % (uint32_t)c;
+    const uint32_t C = 1u << h, R = (1u << (c - 1)) >> h, NP = R + 1 + C;
+    const bool from_cols = k < (uint32_t)h;
+    const uint32_t* src = rc + ((size_t)w * NP + (from_cols ? R + 1 : 0)) * XYZW;
+    const uint32_t bit = from_cols ? k : k - (uint32_t)h;
+    const bool top = k == (uint32_t)c - 1;            // weight B alone has this bit: row R
+    const uint32_t M = top ? 1u : (from_cols ? C : R) / 2;
+    const uint32_t nlanes = blockDim.x / RED_LANES, i0 = threadIdx.x / RED_LANES;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    Jac<ER> p, x;
+    jac_set_inf(p);
+    for (uint32_t i = i0; i < M; i += nlanes) {
+        // i-th index with `bit` set
+        const uint32_t idx = top ? R : (((i >> bit) << (bit + 1)) | (1u << bit) | (i & ((1u << bit) - 1u)));
+        load_jac(x, src + (size_t)idx * XYZW);
+        jac_add(p, p, x);
+    }
+    wave_group_sum_r(p, RED_FOLD);
+    if (lane < (uint32_t)RED_LANES) store_jac(part + wave * XYZW, p);
+    __syncthreads();
+    if (wave != 0) return;
+    const uint32_t jw = lane / RED_LANES;
+    if (jw < nw) load_jac(p, part + jw * XYZW); else jac_set_inf(p);
+    uint32_t G = 1;
+    while (G < nw) G <<= 1;
+    wave_group_sum_r(p, G);
+    if (lane < (uint32_t)RED_LANES) store_jac(planes + ((size_t)w * c + k) * XYZW, p);
+}
+
 // Horner over the window sums, high to low, c doublings between windows (multiexp.tcc:612-629),
 // by one wave.  Prime-field groups with N < 16 limbs run the whole chain on lane-split
 // coordinates (wide.cuh: one limb per lane, four products per step in the four DPP rows, ~3x
@@ -1499,6 +1578,13 @@ __global__ void __launch_bounds__(64) k_horner(const uint32_t* __restrict__ wind
     Jac<E> res;
     horner_chain(res, window_sums, W, c, init);
     if (threadIdx.x == 0) store_out(out, res, form);
+}
+
+// window sum = sum_k 2^k planes[w][k]: the Horner chain with ONE doubling between planes, one wave per window
+__global__ void __launch_bounds__(64) k_window_horner(const uint32_t* __restrict__ planes, int c, uint32_t* __restrict__ out) {
+    Jac<E> res;
+    horner_chain(res, planes + (size_t)blockIdx.x * c * XYZW, c, 1, nullptr);
+    if (threadIdx.x == 0) store_jac(out + (size_t)blockIdx.x * XYZW, res);
 }
 
 // plain sum of k engine-Jacobian points by one wave: the Horner chain with no doublings, i.e. on
@@ -2188,6 +2274,30 @@ void l_sum_block(hipStream_t st, const uint32_t* in, int W, uint32_t M, uint32_t
     const unsigned threads = (unsigned)((M * RED_LANES + 63) / 64 * 64);
     hipLaunchKernelGGL(k_sum_block, dim3(W), dim3(threads), 0, st, in, W, M, out);
 }
+// rc: W * (R + 1 + C) points, planes: W * c points, out: W points (see k_bucket_sums)
+void l_reduce_rowcol(hipStream_t st, const uint32_t* buckets, int W, uint32_t B, int c, uint32_t q_row, uint32_t q_col,
+                     uint32_t* rc, uint32_t* planes, uint32_t* out) {
+    const int h = c / 2;   // ceil((c - 1) / 2) column bits
+    const uint32_t C = 1u << h, R = B >> h;
+    // lanes of one sum: len / q <= RED_FOLD, q a power of two >= 1
+    auto fit = [](uint32_t len, uint32_t q) {
+        if (q < 1) q = 1;
+        while (q & (q - 1)) q &= q - 1;
+        if (q > len) q = len;
+        while (len / q > RED_FOLD) q <<= 1;
+        return q;
+    };
+    q_row = fit(C, q_row);
+    q_col = fit(R, q_col);
+    const size_t row_lanes = (size_t)W * (R + 1) * (C / q_row) * RED_LANES, col_lanes = (size_t)W * C * (R / q_col) * RED_LANES;
+    const unsigned row_blocks = blocks_for(row_lanes, 64), col_blocks = blocks_for(col_lanes, 64);
+    hipLaunchKernelGGL(k_bucket_sums, dim3(row_blocks + col_blocks), dim3(64), 0, st, buckets, W, B, h, q_row, q_col, row_blocks, rc);
+    const uint32_t maxm = (C > R ? C : R) / 2;
+    unsigned threads = (unsigned)((maxm * RED_LANES + 63) / 64 * 64);
+    threads = threads < 64 ? 64 : (threads > 256 ? 256 : threads);
+    hipLaunchKernelGGL(k_plane_sums, dim3((unsigned)(W * c)), dim3(threads), 0, st, rc, W, c, h, planes);
+    hipLaunchKernelGGL(k_window_horner, dim3((unsigned)W), dim3(64), 0, st, planes, c, out);
+}
 void l_horner(hipStream_t st, const uint32_t* window_sums, int W, int c, int form, const uint32_t* init, uint32_t* out) {
     hipLaunchKernelGGL(k_horner, dim3(1), dim3(64), 0, st, window_sums, W, c, form, init, out);
 }
@@ -2276,7 +2386,7 @@ void l_madd_bench(hipStream_t st, const uint32_t* pts, uint32_t* out, size_t nth
 const group_vtable g_vt = {
     GP::CURVE, GP::GROUP, FRW, EW, FQ::N, FR::BITS, GP::LIBFF_PROJECTIVE ? 1 : 0, (int)RED_FOLD, FR::R,
     GLV::BOUND_LOG2_X1000, GP::SUBGROUP_CHECK == 0 ? 1 : 0, GLV::LAMBDA, l_endo_points, l_glv_digits,
-    l_import_bases, l_precompute_table, l_count, l_scatter, l_scalar_stats, l_sort, l_accumulate, l_accumulate_resident_lanes, l_accumulate_fixup, l_reduce_segments, l_sum_butterfly, l_sum_block, l_horner, l_sum_points,
+    l_import_bases, l_precompute_table, l_count, l_scatter, l_scalar_stats, l_sort, l_accumulate, l_accumulate_resident_lanes, l_accumulate_fixup, l_reduce_segments, l_sum_butterfly, l_sum_block, l_reduce_rowcol, l_horner, l_sum_points,
     l_gen_bases_seq, l_export_affine, l_ffi_decode_points, l_ffi_decode_scalars, l_ffi_encode_point, l_disk_decode, l_disk_decode_compressed, l_fixed_base_exp, l_field_op, l_group_op, l_digits, l_mul_bench, l_madd_bench,
 };
 

@@ -475,7 +475,7 @@ for curve, group, n in ((0, 1, 20001), (1, 2, 12007)):
     one = port.fr_from_bigint(curve, np.array([[1] + [0] * (sc.shape[1] - 1)], dtype=np.uint64))[0]
     sc[5::7] = 0
     sc[3::11] = one
-    zeros, ones = len(range(5, n, 7)), len([i for i in range(3, n, 11) if i %% 7 != 5])
+    ones, zeros = len(range(3, n, 11)), len([i for i in range(5, n, 7) if i %% 11 != 3])   # the ones overwrite some zeros
     want = port.multi_exp(curve, group, bases, sc, port.BDLO12_SIGNED, port.FORM_SPECIAL, chunks=8, omp=True)
     # host entry, 5 / 3 ranges
     got = e1.multi_exp(curve, group, bases, sc, base_form=libff_amd.multi_exp_base_form_special)
