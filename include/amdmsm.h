@@ -239,6 +239,10 @@ int amdmsm_multi_exp_stream_with_precompute_file(amdmsm_ctx *ctx, int curve, int
 int amdmsm_batch_exp(amdmsm_ctx *ctx, int curve, int group, size_t scalar_size, size_t window,
                      const void *g_xyz, const void *scalars, size_t n, const void *coeff,
                      int scalars_plain, void *out_xyz);
+/* device times (ms) of the context's last amdmsm_batch_exp: [0] inputs host -> device, [1] window table
+ * (get_window_table, multiexp.tcc:809-846; 0 when the table of the previous call -- same group, scalar_size,
+ * window and g -- was still resident), [2] the exponentiations (batch_exp's loop, :874-912), [3] results back */
+int amdmsm_get_batch_exp_timings(amdmsm_ctx *ctx, float ms[4]);
 
 /* ---- device-resident entry points (all pointers are HBM addresses) ---- */
 int amdmsm_import_bases_device(amdmsm_ctx *ctx, int curve, int group, const void *d_src_xyz,

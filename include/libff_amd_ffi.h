@@ -38,6 +38,10 @@ extern "C" {
 #endif
 
 bool amdmsm_ffi_set_device(int device);
+/* device times (ms) of the last call of any function below: [0] inputs host -> device, [1] decoding and
+ * validation of every element (group_element_read's checks, ffi_serialization.tcc:150-171, on the device),
+ * [2] the MSM and the encoding of its result */
+bool amdmsm_ffi_last_timings(float ms[3]);
 
 #ifndef AMDMSM_FFI_NO_REFERENCE_SYMBOLS
 /* ffi/ffi.h:19-38 (bls12_377: Fr 32 B, G1 96 B) and :61-80 (bw6_761: Fr 48 B, G1 192 B); ffi.cpp:16-54.

@@ -65,6 +65,15 @@ struct base_entry {
     size_t bytes() const { return n * aff_bytes * (d_endo ? 2 : 1); }
 };
 
+// fixed-base exponentiation state kept between amdmsm_batch_exp calls: buffers and the resident window table
+struct fb_state {
+    grow_buf small, table, table_aff, out;
+    bool valid = false;
+    int curve = 0, group = 0;
+    size_t scalar_size = 0, window = 0;
+    unsigned char g[3 * 24 * 2 * 4] = {};   // the generator the resident table was built from
+};
+
 struct amdmsm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -86,7 +95,9 @@ struct amdmsm_ctx {
     hipEvent_t bases_ready = nullptr, host_done = nullptr;
     std::vector<base_entry> bases;
     uint64_t next_base_id = 1, use_clock = 0;
-    float host_ms[4] = {};                        // last host-buffer call: scalars H2D, bases H2D+import, MSM, total
+    fb_state fb;
+    hipEvent_t aux_ev[5] = {};                    // phases of the last amdmsm_batch_exp
+    float aux_ms[4] = {};
     std::string err;
     std::recursive_mutex mu;                      // one call at a time per context (entries nest)
 };
@@ -351,8 +362,13 @@ int make_plan(const group_vtable *vt, size_t n, int c_req, int L_req, plan_t &p,
         p.rowcol = rc_env != 0 && p.c >= rc_min_c;
         const int h = p.c / 2;
         const size_t C = (size_t)1 << h, R = p.B >> h;
+        // (measured, tools/exp_rowcol.sh: alt_bn128 G1 2^20 q = 4 / 8 / 16 -> reduction phase 0.46 / 0.51 / 0.51 ms, 2^23
+        // 1.09 / 0.87 / 0.79; the wide fields, whose kernels hold one wave per SIMD, want one round of lanes:
+        // bw6_761 G1 2^21 q = 8 / 16 / 32 -> 5.41 / 5.03 / 6.24 ms, bls12_377 G2 2^21 2.72 / 2.57 / 3.07)
+        const bool one_wave = vt->fq_words >= 24 || vt->el_words > vt->fq_words;
+        const size_t lane_budget = one_wave ? 70000 : 140000;
         uint32_t q = 4;
-        while (q < 64 && (size_t)p.W * p.B * red_lanes * 2 / q > (size_t)140000) q <<= 1;
+        while (q < 64 && (size_t)p.W * p.B * red_lanes * 2 / q > lane_budget) q <<= 1;
         p.q_row = qr_env > 0 ? (uint32_t)qr_env : q;
         p.q_col = qc_env > 0 ? (uint32_t)qc_env : q;
         p.rc_points = R + 1 + C;
@@ -704,6 +720,12 @@ int amdmsm_ctx_create(int device, amdmsm_ctx **out) {
             }
         }
     }
+    for (auto &e : ctx->aux_ev) {
+        if (hipEventCreate(&e) != hipSuccess) {
+            delete ctx;
+            return AMDMSM_ERR_HIP;
+        }
+    }
     for (auto &sl : ctx->slots) {
         bool ok = hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) == hipSuccess;
         for (auto &e : sl.tail_done) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
@@ -745,7 +767,11 @@ void amdmsm_ctx_destroy(amdmsm_ctx *ctx) {
             }
         }
         if (ctx->chunk_partials) (void)hipFree(ctx->chunk_partials);
-        for (grow_buf *b : {&ctx->hb_src, &ctx->hb_aff, &ctx->hb_sc, &ctx->hb_out, &ctx->hb_stats}) {
+        for (auto &e : ctx->aux_ev) {
+            if (e) (void)hipEventDestroy(e);
+        }
+        for (grow_buf *b : {&ctx->hb_src, &ctx->hb_aff, &ctx->hb_sc, &ctx->hb_out, &ctx->hb_stats, &ctx->fb.small, &ctx->fb.table,
+                            &ctx->fb.table_aff, &ctx->fb.out}) {
             if (b->p) (void)hipFree(b->p);
         }
         for (auto &be : ctx->bases) {
@@ -1846,43 +1872,66 @@ int amdmsm_batch_exp(amdmsm_ctx *ctx, int curve, int group, size_t scalar_size, 
     if (window < 1 || window > 22 || scalar_size < 1 || scalar_size > (size_t)vt->fr_words * 32) {
         return fail(ctx, AMDMSM_ERR_BAD_ARG, "window / scalar_size");
     }
-    const size_t xyz_bytes = (size_t)vt->el_words * 12, fr_bytes = (size_t)vt->fr_words * 4;
+    const size_t xyz_bytes = (size_t)vt->el_words * 12, aff_bytes = (size_t)vt->el_words * 8, fr_bytes = (size_t)vt->fr_words * 4;
     const size_t outerc = (scalar_size + window - 1) / window;
+    const size_t entries = outerc << window;
     hipStream_t st = ctx->stream;
-    void *d_g = nullptr, *d_go = nullptr, *d_tab = nullptr, *d_sc = nullptr, *d_cf = nullptr, *d_out = nullptr;
-    auto cleanup = [&]() {
-        for (void *p : {d_g, d_go, d_tab, d_sc, d_cf, d_out}) {
-            if (p) (void)hipFree(p);
-        }
-    };
-#define TRY_CLEAN(expr)                                                                          \
-    do {                                                                                         \
-        hipError_t e_ = (expr);                                                                  \
-        if (e_ != hipSuccess) {                                                                  \
-            cleanup();                                                                           \
-            return fail(ctx, AMDMSM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
-        }                                                                                        \
-    } while (0)
-    TRY_CLEAN(hipMalloc(&d_g, xyz_bytes));
-    TRY_CLEAN(hipMalloc(&d_go, outerc * xyz_bytes));
-    TRY_CLEAN(hipMalloc(&d_tab, (outerc << window) * xyz_bytes));
-    TRY_CLEAN(hipMalloc(&d_sc, n ? n * fr_bytes : 16));
-    TRY_CLEAN(hipMalloc(&d_out, n ? n * xyz_bytes : 16));
-    TRY_CLEAN(hipMemcpyAsync(d_g, g_xyz, xyz_bytes, hipMemcpyHostToDevice, st));
-    if (n) TRY_CLEAN(hipMemcpyAsync(d_sc, scalars, n * fr_bytes, hipMemcpyHostToDevice, st));
-    if (coeff) {
-        TRY_CLEAN(hipMalloc(&d_cf, fr_bytes));
-        TRY_CLEAN(hipMemcpyAsync(d_cf, coeff, fr_bytes, hipMemcpyHostToDevice, st));
+    // Device buffers are the context's (grow-only), and the affine window table stays in HBM: a key
+    // generator calls batch_exp many times with one table (libsnark r1cs_gg_ppzksnark_generator), so a
+    // call with the same (group, scalar_size, window, g) as the last one skips get_window_table's work.
+    fb_state &fb = ctx->fb;
+    const bool same_table = fb.valid && fb.curve == curve && fb.group == group && fb.scalar_size == scalar_size &&
+                            fb.window == window && memcmp(fb.g, g_xyz, xyz_bytes) == 0;
+    int rc = ensure_buf(ctx, fb.small, 2 * xyz_bytes + outerc * xyz_bytes + 64);
+    if (rc == AMDMSM_OK && !same_table) {
+        fb.valid = false;
+        rc = ensure_buf(ctx, fb.table, entries * xyz_bytes);
+        if (rc == AMDMSM_OK) rc = ensure_buf(ctx, fb.table_aff, entries * aff_bytes);
     }
-    vt->fixed_base_exp(st, (const uint32_t *)d_g, (int)scalar_size, (int)window, (const uint32_t *)d_sc, n,
-                       scalars_plain ? 0 : 1, (const uint32_t *)d_cf, AMDMSM_OUT_LIBFF, (uint32_t *)d_go,
-                       (uint32_t *)d_tab, (uint32_t *)d_out);
-    TRY_CLEAN(hipGetLastError());
-    if (n) TRY_CLEAN(hipMemcpyAsync(out_xyz, d_out, n * xyz_bytes, hipMemcpyDeviceToHost, st));
-    TRY_CLEAN(hipStreamSynchronize(st));
-    cleanup();
+    if (rc == AMDMSM_OK) rc = ensure_buf(ctx, ctx->hb_sc, n ? n * fr_bytes : 16);
+    if (rc == AMDMSM_OK) rc = ensure_buf(ctx, fb.out, n ? n * xyz_bytes : 16);
+    if (rc) return rc;
+    char *d_g = (char *)fb.small.p, *d_cf = d_g + xyz_bytes, *d_go = d_cf + xyz_bytes;
+    HIP_TRY(ctx, hipEventRecord(ctx->aux_ev[0], st));
+    if (!same_table) {
+        HIP_TRY(ctx, hipMemcpyAsync(d_g, g_xyz, xyz_bytes, hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, hipMemsetAsync(fb.table.p, 0, entries * xyz_bytes, st));   // rows shorter than 2^window: infinity beyond
+    }
+    if (n) HIP_TRY(ctx, hipMemcpyAsync(ctx->hb_sc.p, scalars, n * fr_bytes, hipMemcpyHostToDevice, st));
+    if (coeff) HIP_TRY(ctx, hipMemcpyAsync(d_cf, coeff, fr_bytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipEventRecord(ctx->aux_ev[1], st));
+    // table build and exponentiation are separate launches of the same entry: time them apart
+    if (!same_table) {
+        vt->fixed_base_exp(st, (const uint32_t *)d_g, (int)scalar_size, (int)window, nullptr, 0, 0, nullptr, AMDMSM_OUT_LIBFF,
+                           (uint32_t *)d_go, (uint32_t *)fb.table.p, (uint32_t *)fb.table_aff.p, 1, nullptr);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    HIP_TRY(ctx, hipEventRecord(ctx->aux_ev[2], st));
+    vt->fixed_base_exp(st, (const uint32_t *)d_g, (int)scalar_size, (int)window, (const uint32_t *)ctx->hb_sc.p, n,
+                       scalars_plain ? 0 : 1, coeff ? (const uint32_t *)d_cf : nullptr, AMDMSM_OUT_LIBFF, (uint32_t *)d_go,
+                       (uint32_t *)fb.table.p, (uint32_t *)fb.table_aff.p, 0, (uint32_t *)fb.out.p);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->aux_ev[3], st));
+    if (n) HIP_TRY(ctx, hipMemcpyAsync(out_xyz, fb.out.p, n * xyz_bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipEventRecord(ctx->aux_ev[4], st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    for (int i = 0; i < 4; ++i) (void)hipEventElapsedTime(&ctx->aux_ms[i], ctx->aux_ev[i], ctx->aux_ev[i + 1]);
+    fb.valid = true;
+    fb.curve = curve;
+    fb.group = group;
+    fb.scalar_size = scalar_size;
+    fb.window = window;
+    memcpy(fb.g, g_xyz, xyz_bytes);
     return AMDMSM_OK;
-#undef TRY_CLEAN
+}
+
+// device times of the last amdmsm_batch_exp of this context: ms[0] inputs host -> device, ms[1] window table
+// (0 when the resident table was reused), ms[2] the exponentiations (k_fb_exp), ms[3] results device -> host
+int amdmsm_get_batch_exp_timings(amdmsm_ctx *ctx, float ms[4]) {
+    if (!ctx || !ms) return AMDMSM_ERR_BAD_ARG;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    for (int i = 0; i < 4; ++i) ms[i] = ctx->aux_ms[i];
+    return AMDMSM_OK;
 }
 
 int amdmsm_batch_to_special(amdmsm_ctx *ctx, int curve, int group, void *elems_xyz, size_t stride_bytes, size_t n) {

@@ -37,9 +37,15 @@ struct dev_buf {
     }
 };
 dev_buf g_in, g_aff, g_sc_in, g_sc, g_small;   // g_small: status word, result record, encoded result
+hipEvent_t g_ev[4] = {};                       // start, inputs on the device, decoded + validated, result encoded
+float g_ms[3] = {};
 
 amdmsm_ctx *ffi_ctx_locked() {
     if (!g_ctx && amdmsm_ctx_create(g_device, &g_ctx) != AMDMSM_OK) g_ctx = nullptr;
+    if (g_ctx && !g_ev[0]) {
+        dev_guard guard(g_device);
+        for (auto &e : g_ev) (void)hipEventCreate(&e);
+    }
     return g_ctx;
 }
 
@@ -69,12 +75,17 @@ bool ffi_multiexp(int curve, int group, const void *bases, size_t bases_size, co
     }
     char *d_status = (char *)g_small.p, *d_res = d_status + 256, *d_out = d_res + 3 * coord;
     if (hipMemsetAsync(d_status, 0, 4, st) != hipSuccess) return false;
+    (void)hipEventRecord(g_ev[0], st);
     if (n) {
         if (hipMemcpyAsync(g_in.p, bases, bases_size, hipMemcpyHostToDevice, st) != hipSuccess) return false;
         if (hipMemcpyAsync(g_sc_in.p, scalars, scalars_size, hipMemcpyHostToDevice, st) != hipSuccess) return false;
+        (void)hipEventRecord(g_ev[1], st);
         vt->ffi_decode_points(st, (const uint32_t *)g_in.p, n, (uint32_t *)g_aff.p, (uint32_t *)d_status);
         vt->ffi_decode_scalars(st, (const uint32_t *)g_sc_in.p, n, (uint32_t *)g_sc.p, (uint32_t *)d_status);
+    } else {
+        (void)hipEventRecord(g_ev[1], st);
     }
+    (void)hipEventRecord(g_ev[2], st);
     // The MSM is enqueued behind the validation without waiting for its verdict (one
     // synchronisation per call); a rejected input costs a wasted MSM, an accepted one nothing.
     amdmsm_opts o = AMDMSM_OPTS_INIT;
@@ -87,12 +98,15 @@ bool ffi_multiexp(int curve, int group, const void *bases, size_t bases_size, co
         return false;
     }
     vt->ffi_encode_point(st, (const uint32_t *)d_res, (uint32_t *)d_out);
+    (void)hipEventRecord(g_ev[3], st);
     unsigned status = 0;
     unsigned char tmp[2 * 2 * 96];   // largest element: bw6_761 G1/G2 or bls12_377 G2, 192 bytes
     if (2 * coord > sizeof(tmp)) return false;
     if (hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, st) != hipSuccess) return false;
     if (hipMemcpyAsync(tmp, d_out, 2 * coord, hipMemcpyDeviceToHost, st) != hipSuccess) return false;
-    if (hipStreamSynchronize(st) != hipSuccess || status != 0) return false;
+    if (hipStreamSynchronize(st) != hipSuccess) return false;
+    for (int i = 0; i < 3; ++i) (void)hipEventElapsedTime(&g_ms[i], g_ev[i], g_ev[i + 1]);
+    if (status != 0) return false;
     memcpy(out, tmp, 2 * coord);   // output untouched on every failure path above
     return true;
 }
@@ -152,6 +166,15 @@ bool bw6_761_g1_mul(const void *p_g1, size_t p_g1_size, const void *s_fr, size_t
     return ffi_g1_mul(AMDMSM_CURVE_BW6_761, p_g1, p_g1_size, s_fr, s_fr_size, out_g1, out_g1_size);
 }
 #endif
+
+// device times (ms) of the last FFI call: [0] inputs host -> device, [1] decoding + validation of every element
+// (range, curve equation, subgroup: k_ffi_decode_points / _scalars), [2] the MSM and the encoding of its result
+bool amdmsm_ffi_last_timings(float ms[3]) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    if (!g_ctx || !ms) return false;
+    for (int i = 0; i < 3; ++i) ms[i] = g_ms[i];
+    return true;
+}
 
 bool amdmsm_ffi_set_device(int device) {
     std::lock_guard<std::mutex> lock(g_mu);

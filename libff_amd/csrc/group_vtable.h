@@ -161,10 +161,11 @@ struct group_vtable {
     void (*disk_decode_compressed)(hipStream_t, const uint32_t* src, size_t n, uint32_t* dst_affine, uint32_t* status);
     // fixed-base batch exponentiation: out[i] = (coeff *) scalars[i] * g via a window table
     // (get_window_table / windowed_exp / batch_exp[_with_coeff], multiexp.tcc:809-947);
-    // gouter: outerc points, table: outerc * 2^window points, outerc = ceil(scalar_size / window)
+    // gouter: outerc points, table: outerc * 2^window points (scratch: must be zero-filled), table_aff: as many compact
+    // affine records, outerc = ceil(scalar_size / window); build_table = 0 reuses table_aff as a previous call left it
     void (*fixed_base_exp)(hipStream_t, const uint32_t* g_xyz, int scalar_size, int window, const uint32_t* scalars,
                            size_t n, int mont, const uint32_t* coeff, int form, uint32_t* gouter, uint32_t* table,
-                           uint32_t* out);
+                           uint32_t* table_aff, int build_table, uint32_t* out);
 
     // ---- test hooks (parity of the primitives against the oracle) ----------
     // coordinate-field op over arrays: 0 mul 1 sqr 2 add 3 sub 4 neg 5 inverse

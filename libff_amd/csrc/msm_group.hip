@@ -1860,7 +1860,50 @@ __global__ void __launch_bounds__(TPB) k_fb_table_level(const uint32_t* __restri
     store_jac(row + j * XYZW, p);
 }
 
-__global__ void __launch_bounds__(TPB) k_fb_exp(const uint32_t* __restrict__ table, const uint32_t* __restrict__ scalars,
+// The table made affine once (compact records, (0, 0) = zero), FB_NORM_K entries per lane sharing one
+// inversion (Montgomery's trick, as k_import_bases): the per-scalar loop below then adds table entries
+// with the mixed addition of the bucket accumulation (8M + 2S on XYZZ accumulators) instead of the full
+// Jacobian addition with its equality pre-test (11M + 5S + 6M + 2S, alt_bn128_g1.cpp:164).
+constexpr int FB_NORM_K = 32;
+__global__ void __launch_bounds__(TPB) k_fb_table_affine(const uint32_t* __restrict__ table, size_t n, uint32_t* __restrict__ dst) {
+    const size_t i0 = gtid() * FB_NORM_K;
+    if (i0 >= n) return;
+    const size_t i1 = (i0 + FB_NORM_K < n) ? i0 + FB_NORM_K : n;
+    E acc;
+    el_one(acc);
+    for (size_t i = i0; i < i1; ++i) {
+        Jac<E> p;
+        load_jac(p, table + i * XYZW);
+        if (jac_is_inf(p)) continue;
+        el_store(dst + i * AFFW, acc);   // prefix product of the Z's before this entry
+        el_mul(acc, acc, p.z);
+    }
+    E inv;
+    el_inv(inv, acc);
+    for (size_t i = i1; i-- > i0;) {
+        Jac<E> p;
+        load_jac(p, table + i * XYZW);
+        Aff<E> a;
+        if (jac_is_inf(p)) {
+            el_zero(a.x);
+            el_zero(a.y);
+        } else {
+            E pre, zi, z2;
+            el_load(pre, dst + i * AFFW);
+            el_mul(zi, inv, pre);      // Z_i^-1
+            el_mul(inv, inv, p.z);
+            el_sqr(z2, zi);
+            el_mul(a.x, p.x, z2);
+            el_mul(z2, z2, zi);
+            el_mul(a.y, p.y, z2);
+        }
+        store_aff(dst + i * AFFW, a);
+    }
+}
+
+// res[i] = (coeff *) v[i] * g (windowed_exp, multiexp.tcc:848-872): one lane per scalar, one mixed addition
+// per nonzero window digit into an XYZZ accumulator, table entries affine
+__global__ void __launch_bounds__(TPB) k_fb_exp(const uint32_t* __restrict__ table_aff, const uint32_t* __restrict__ scalars,
                                                 size_t n, int mont, const uint32_t* __restrict__ coeff, int scalar_size,
                                                 int window, int form, uint32_t* __restrict__ out) {
     const size_t i = gtid();
@@ -1882,8 +1925,9 @@ __global__ void __launch_bounds__(TPB) k_fb_exp(const uint32_t* __restrict__ tab
     const int outerc = (scalar_size + window - 1) / window;
     const size_t row_len = (size_t)1 << window;
     const uint32_t wmask = (1u << window) - 1u;
-    Jac<E> res, e;
-    jac_set_inf(res);   // powers_of_g[0][0] = zero
+    Xyzz<E> acc;
+    Aff<E> e;
+    xyzz_set_inf(acc);   // powers_of_g[0][0] = zero
     uint64_t buf = 0;
     int nbits = 0, outer = 0;
 #pragma unroll
@@ -1895,8 +1939,8 @@ __global__ void __launch_bounds__(TPB) k_fb_exp(const uint32_t* __restrict__ tab
             buf >>= window;
             nbits -= window;
             if (inner) {
-                load_jac(e, table + ((size_t)outer * row_len + inner) * XYZW);
-                jac_add(res, res, e);
+                load_aff(e, table_aff + ((size_t)outer * row_len + inner) * AFFW);
+                xyzz_madd(acc, e);
             }
             ++outer;
         }
@@ -1905,11 +1949,13 @@ __global__ void __launch_bounds__(TPB) k_fb_exp(const uint32_t* __restrict__ tab
         const uint32_t inner = (uint32_t)buf & wmask;
         buf >>= window;
         if (inner) {
-            load_jac(e, table + ((size_t)outer * row_len + inner) * XYZW);
-            jac_add(res, res, e);
+            load_aff(e, table_aff + ((size_t)outer * row_len + inner) * AFFW);
+            xyzz_madd(acc, e);
         }
         ++outer;
     }
+    Jac<E> res;
+    xyzz_to_jac(res, acc);
     store_out(out + i * XYZW, res, form);
 }
 
@@ -2331,18 +2377,28 @@ void l_disk_decode_compressed(hipStream_t st, const uint32_t* src, size_t n, uin
     if (!n) return;
     hipLaunchKernelGGL(k_disk_decode_compressed, dim3(blocks_for(n, 64)), dim3(64), 0, st, src, n, dst, status);
 }
-// table: outerc * 2^window points, gouter: outerc points
+// table: outerc * 2^window Jacobian points of scratch, gouter: outerc points, table_aff: outerc * 2^window
+// compact affine records (what k_fb_exp reads).  build_table = 0: table_aff already holds the table of this
+// (g, scalar_size, window) -- the caller keeps it between calls.
 void l_fixed_base_exp(hipStream_t st, const uint32_t* g_xyz, int scalar_size, int window, const uint32_t* scalars, size_t n,
-                      int mont, const uint32_t* coeff, int form, uint32_t* gouter, uint32_t* table, uint32_t* out) {
+                      int mont, const uint32_t* coeff, int form, uint32_t* gouter, uint32_t* table, uint32_t* table_aff,
+                      int build_table, uint32_t* out) {
     const int outerc = (scalar_size + window - 1) / window;
-    hipLaunchKernelGGL(k_fb_gouter, dim3(1), dim3(64), 0, st, g_xyz, outerc, window, gouter);
-    for (int level = 0; level < window; ++level) {
-        const size_t per_level = level == 0 ? 2 : ((size_t)1 << level);
-        hipLaunchKernelGGL(k_fb_table_level, dim3(blocks_for((size_t)outerc * per_level)), dim3(TPB), 0, st, gouter, outerc,
-                           window, scalar_size, level, table);
+    if (build_table) {
+        hipLaunchKernelGGL(k_fb_gouter, dim3(1), dim3(64), 0, st, g_xyz, outerc, window, gouter);
+        for (int level = 0; level < window; ++level) {
+            const size_t per_level = level == 0 ? 2 : ((size_t)1 << level);
+            hipLaunchKernelGGL(k_fb_table_level, dim3(blocks_for((size_t)outerc * per_level)), dim3(TPB), 0, st, gouter, outerc,
+                               window, scalar_size, level, table);
+        }
+        // (entries past the shorter last row are never addressed by k_fb_exp; they read as whatever the scratch held,
+        // so the row is cleared first: an all-zero Jacobian record has Z == 0 = infinity)
+        const size_t entries = (size_t)outerc << window;
+        hipLaunchKernelGGL(k_fb_table_affine, dim3(blocks_for((entries + FB_NORM_K - 1) / FB_NORM_K)), dim3(TPB), 0, st, table,
+                           entries, table_aff);
     }
     if (n) {
-        hipLaunchKernelGGL(k_fb_exp, dim3(blocks_for(n)), dim3(TPB), 0, st, table, scalars, n, mont, coeff, scalar_size,
+        hipLaunchKernelGGL(k_fb_exp, dim3(blocks_for(n)), dim3(TPB), 0, st, table_aff, scalars, n, mont, coeff, scalar_size,
                            window, form, out);
     }
 }

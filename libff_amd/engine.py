@@ -46,7 +46,7 @@ EXPORTED_SYMBOLS = [
     "amdmsm_bdlo12_signed_optimal_c", "amdmsm_multi_exp", "amdmsm_multi_exp_filter_one_zero",
     "amdmsm_multi_exp_multi", "amdmsm_multi_exp_filter_one_zero_multi", "amdmsm_msm_device_multi", "amdmsm_register_bases", "amdmsm_unregister_bases",
     "amdmsm_invalidate_bases",
-    "amdmsm_batch_to_special", "amdmsm_batch_exp", "amdmsm_multi_exp_stream", "amdmsm_multi_exp_stream_file",
+    "amdmsm_batch_to_special", "amdmsm_batch_exp", "amdmsm_get_batch_exp_timings", "amdmsm_multi_exp_stream", "amdmsm_multi_exp_stream_file",
     "amdmsm_multi_exp_stream_compressed", "amdmsm_multi_exp_stream_compressed_file", "amdmsm_disk_decode_device",
     "amdmsm_precompute_num_digits", "amdmsm_multi_exp_stream_with_precompute",
     "amdmsm_multi_exp_stream_with_precompute_file", "amdmsm_precompute_bases_device",
@@ -452,6 +452,12 @@ class Engine:
                                        _np_ptr(out) if n else None)
         self._check(rc, "amdmsm_batch_exp")
         return out
+
+    def batch_exp_timings(self):
+        """device times (ms) of the last batch_exp: inputs H2D, window table (0 = reused), exponentiations, results D2H"""
+        ms = (ctypes.c_float * 4)()
+        self._check(self.lib.amdmsm_get_batch_exp_timings(self.h, ms), "amdmsm_get_batch_exp_timings")
+        return {"h2d_ms": ms[0], "table_ms": ms[1], "exp_ms": ms[2], "d2h_ms": ms[3]}
 
     def sum_points(self, curve, group, points_jacobian, out_form=OUT_AFFINE):
         """Sum of engine-Jacobian partial results (the serial tail of multiexp.tcc:681-687)."""
