@@ -25,6 +25,9 @@ GROUP_FLAGS = {g: ["-DAMDMSM_HOT_INLINE=1", "-DAMDMSM_BENCH_BOTH=1"] for g in GR
 # register budget of the bucket-accumulation kernel: 4 waves per SIMD (128 VGPRs, 3 dwords of
 # scratch) instead of the 137 VGPRs / 3 waves the compiler picks unconstrained: -4 % at 2^20
 GROUP_FLAGS["alt_bn128_g1"] = GROUP_FLAGS["alt_bn128_g1"] + ["-DAMDMSM_ACC_WAVES=4"]
+# overlap mode (several MSMs in flight: the tail of one under the sort and accumulation of the next, engine.cpp
+# amdmsm_ctx::bulk_stream): the tail kernels get the 128 registers three accumulation waves leave of a SIMD
+GROUP_FLAGS["alt_bn128_g1"] = GROUP_FLAGS["alt_bn128_g1"] + ["-DAMDMSM_OVERLAP_OK=1", "-DAMDMSM_TAIL_WAVES=4"]
 # wide fields: unconstrained, the kernel takes 256 VGPRs plus 50..125 AGPRs as spill space and
 # runs ONE wave per SIMD; capped at 256 registers (two waves per SIMD, a little scratch) it is
 # 23-25 % faster (bls12_377 G2 2^21: 28.1 -> 22.9 ms, bw6_761 G1 2^21: 43.8 -> 35.0 ms);

@@ -40,6 +40,7 @@ struct ws_slot {
     hipEvent_t acc_done[MAX_GROUPS - 1] = {}, tail_done[MAX_GROUPS - 1] = {};
     long long last_ticket = -1;   // timing ticket of the call that last used the slot
     bool ev_valid = false;
+    hipEvent_t ov_in = nullptr, ov_acc = nullptr, ov_tail = nullptr;   // overlap mode (see amdmsm_ctx::bulk_stream)
 };
 
 // grow-only device buffer kept by the context between calls (host-buffer entry points)
@@ -93,6 +94,13 @@ struct amdmsm_ctx {
     grow_buf hb_src, hb_aff, hb_sc, hb_out, hb_stats;
     hipStream_t copy_stream = nullptr;
     hipEvent_t bases_ready = nullptr, host_done = nullptr;
+    // Several MSMs in flight (pipeline depth > 1), overlap by construction: the bulk of every MSM -- bucket sort
+    // and accumulation, which fill the device -- is enqueued on ONE stream in call order, its latency-bound tail
+    // (bucket fix-up, reduction, Horner: a few waves, 0.6 ms of dependent chains at 2^20 points) on a second,
+    // high-priority stream.  MSM k+1's sort and accumulation therefore start when MSM k's accumulation ends and
+    // run under MSM k's tail; the accumulation kernel is launched one workgroup per CU short of full occupancy
+    // in this mode so that a tail wave finds registers on every SIMD (group_vtable::accumulate_overlap).
+    hipStream_t bulk_stream = nullptr, tail_stream = nullptr;
     std::vector<base_entry> bases;
     uint64_t next_base_id = 1, use_clock = 0;
     fb_state fb;
@@ -253,7 +261,7 @@ int choose_c(const group_vtable *vt, size_t n, bool glv = false, double *cost_ou
 // its precomputed multiple) to a single bucket set; n is then the number of ENTRIES.
 // glv: n counts the 2 x points digit columns of the endomorphism split
 int make_plan(const group_vtable *vt, size_t n, int c_req, int L_req, plan_t &p, int S_req = 0, int table_digits = 0,
-              int G_req = 0, bool glv = false) {
+              int G_req = 0, bool glv = false, bool overlap = false) {
     if (c_req < 0 || c_req > 24 || c_req == 1) return AMDMSM_ERR_BAD_ARG;
     if (table_digits && (c_req < 2 || c_req > 22)) return AMDMSM_ERR_BAD_ARG;
     if (glv && (table_digits || c_req > 22)) return AMDMSM_ERR_BAD_ARG;
@@ -291,7 +299,7 @@ int make_plan(const group_vtable *vt, size_t n, int c_req, int L_req, plan_t &p,
     // fill whole rounds: k rounds exactly for the smallest k that keeps S <= 128, or simply
     // S = 128 once there are many rounds anyway.
     {
-        const double resident = (double)vt->accumulate_resident_lanes();
+        const double resident = (double)vt->accumulate_resident_lanes(overlap ? 1 : 0);
         const double entries = (double)n * p.W;
         uint32_t S = 8;
         if (entries >= 8.0 * 128.0 * resident) {
@@ -486,6 +494,7 @@ int msm_device_impl(amdmsm_ctx *ctx, const group_vtable *vt, const uint32_t *d_b
                     size_t n, uint32_t *d_out, const amdmsm_opts *opts, int table_digits = 0,
                     const msm_hook *hook = nullptr, const uint32_t *d_endo_resident = nullptr) {
     hipStream_t st = (opts && opts->stream) ? (hipStream_t)opts->stream : ctx->stream;
+    hipStream_t const user_st = st;
     const int form = opts ? opts->out_form : AMDMSM_OUT_LIBFF;
     const int mont = (opts && opts->scalars_plain) ? 0 : 1;
     static const bool atomic_sort = getenv("AMDMSM_SORT") && !strcmp(getenv("AMDMSM_SORT"), "atomic");
@@ -502,12 +511,22 @@ int msm_device_impl(amdmsm_ctx *ctx, const group_vtable *vt, const uint32_t *d_b
     // tuning knobs for experiments: AMDMSM_ACC_S (entries per accumulation lane)
     static const int acc_s_env = getenv("AMDMSM_ACC_S") ? atoi(getenv("AMDMSM_ACC_S")) : 0;
     static const int groups_env = getenv("AMDMSM_WINDOW_GROUPS") ? atoi(getenv("AMDMSM_WINDOW_GROUPS")) : 0;
+    // overlap mode (several MSMs in flight, see amdmsm_ctx::bulk_stream); AMDMSM_OVERLAP=0 leaves the ordering of
+    // concurrent MSMs to the hardware queues as before
+    static const bool overlap_env = !(getenv("AMDMSM_OVERLAP") && atoi(getenv("AMDMSM_OVERLAP")) == 0);
+    const bool overlap = overlap_env && ctx->depth > 1 && vt->accumulate_overlap_ok && !groups_env;
     int rc = make_plan(vt, entries, opts ? opts->window_bits : 0, opts ? opts->segment_len : 0, p, acc_s_env, table_digits,
-                       groups_env, glv);
+                       groups_env, glv, overlap);
     if (rc) return fail(ctx, rc, "bad window_bits / segment_len");
     const int slot_idx = (int)(ctx->next++ % (unsigned)ctx->depth);
     ws_slot &sl = ctx->slots[slot_idx];
     ctx->last_slot = slot_idx;
+    if (overlap) {
+        // the bulk part runs on the context's bulk stream, behind whatever the caller's stream holds now
+        HIP_TRY(ctx, hipEventRecord(sl.ov_in, user_st));
+        st = ctx->bulk_stream;
+        HIP_TRY(ctx, hipStreamWaitEvent(st, sl.ov_in, 0));
+    }
     if (sl.used) HIP_TRY(ctx, hipStreamWaitEvent(st, sl.done, 0));   // previous user of this slot
     rc = ensure_ws(ctx, sl, p.total);
     if (rc) return rc;
@@ -569,13 +588,17 @@ int msm_device_impl(amdmsm_ctx *ctx, const group_vtable *vt, const uint32_t *d_b
         const bool last = g == p.G - 1;
         // accumulation group after group on the caller's stream; the tail of a finished group
         // moves to a side stream
-        hipStream_t ts = last ? st : sl.side[g];
+        hipStream_t ts = last ? (overlap ? ctx->tail_stream : st) : sl.side[g];
         if (g == 0) record(ctx, sl, 2, st);
         vt->accumulate(st, counts + (size_t)w0 * p.B, lists + (size_t)w0 * p.list_stride, p.list_stride, d_bases,
                        buckets + (size_t)w0 * p.B * zzw, pfirst + (size_t)w0 * p.T * zzw, plast + (size_t)w0 * p.T * zzw,
-                       cont + (size_t)w0 * p.T, wg, p.B, p.S, p.T, endo_pts, n);
+                       cont + (size_t)w0 * p.T, wg, p.B, p.S, p.T, endo_pts, n, overlap ? 1 : 0);
         if (last) {
             record(ctx, sl, 3, st);
+            if (overlap) {
+                HIP_TRY(ctx, hipEventRecord(sl.ov_acc, st));
+                HIP_TRY(ctx, hipStreamWaitEvent(ts, sl.ov_acc, 0));
+            }
         } else {
             HIP_TRY(ctx, hipEventRecord(sl.acc_done[g], st));
             HIP_TRY(ctx, hipStreamWaitEvent(ts, sl.acc_done[g], 0));
@@ -607,12 +630,20 @@ int msm_device_impl(amdmsm_ctx *ctx, const group_vtable *vt, const uint32_t *d_b
         }
         // Horner over this group's windows, continuing from the groups above
         if (g > 0) HIP_TRY(ctx, hipStreamWaitEvent(ts, sl.tail_done[g - 1], 0));
-        if (last) record(ctx, sl, 4, st);
+        if (last) record(ctx, sl, 4, ts);
         vt->horner(ts, src, wg, p.c, last ? form : (int)AMDMSM_OUT_JACOBIAN, g > 0 ? partial + (size_t)(g - 1) * xyzw : nullptr,
                    last ? d_out : partial + (size_t)g * xyzw);
         if (!last) HIP_TRY(ctx, hipEventRecord(sl.tail_done[g], ts));
     }
-    record(ctx, sl, 5, st);
+    if (overlap) {
+        // the result (and the slot) belong to the caller's stream again once the tail has run
+        record(ctx, sl, 5, ctx->tail_stream);
+        HIP_TRY(ctx, hipEventRecord(sl.ov_tail, ctx->tail_stream));
+        HIP_TRY(ctx, hipStreamWaitEvent(user_st, sl.ov_tail, 0));
+        st = user_st;
+    } else {
+        record(ctx, sl, 5, st);
+    }
     if (ctx->timing) sl.last_ticket = (long long)ctx->ticket++;
     sl.ev_valid = ctx->timing;
     HIP_TRY(ctx, hipEventRecord(sl.done, st));
@@ -726,8 +757,18 @@ int amdmsm_ctx_create(int device, amdmsm_ctx **out) {
             return AMDMSM_ERR_HIP;
         }
     }
+    {
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if (hipStreamCreateWithPriority(&ctx->bulk_stream, hipStreamNonBlocking, least) != hipSuccess ||
+            hipStreamCreateWithPriority(&ctx->tail_stream, hipStreamNonBlocking, greatest) != hipSuccess) {
+            delete ctx;
+            return AMDMSM_ERR_HIP;
+        }
+    }
     for (auto &sl : ctx->slots) {
         bool ok = hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) == hipSuccess;
+        for (hipEvent_t *e : {&sl.ov_in, &sl.ov_acc, &sl.ov_tail}) ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
         for (auto &e : sl.tail_done) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
         for (auto &e : sl.acc_done) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
         for (auto &q : sl.side) ok = ok && hipStreamCreateWithFlags(&q, hipStreamNonBlocking) == hipSuccess;
@@ -748,6 +789,9 @@ void amdmsm_ctx_destroy(amdmsm_ctx *ctx) {
         for (auto &sl : ctx->slots) {
             if (sl.ws) (void)hipFree(sl.ws);
             if (sl.done) (void)hipEventDestroy(sl.done);
+            for (hipEvent_t e : {sl.ov_in, sl.ov_acc, sl.ov_tail}) {
+                if (e) (void)hipEventDestroy(e);
+            }
             for (auto &e : sl.acc_done) {
                 if (e) (void)hipEventDestroy(e);
             }
@@ -781,6 +825,8 @@ void amdmsm_ctx_destroy(amdmsm_ctx *ctx) {
         if (ctx->bases_ready) (void)hipEventDestroy(ctx->bases_ready);
         if (ctx->host_done) (void)hipEventDestroy(ctx->host_done);
         if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+        if (ctx->bulk_stream) (void)hipStreamDestroy(ctx->bulk_stream);
+        if (ctx->tail_stream) (void)hipStreamDestroy(ctx->tail_stream);
         if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     }
     delete ctx;

@@ -115,10 +115,13 @@ struct group_vtable {
     void (*accumulate)(hipStream_t, const uint32_t* ends, const uint32_t* lists, size_t list_stride,
                        const uint32_t* bases_affine, uint32_t* buckets, uint32_t* part_first, uint32_t* part_last,
                        uint32_t* cont_bucket, int W, uint32_t B, uint32_t S, uint32_t T, const uint32_t* endo_points,
-                       size_t n_real);
+                       size_t n_real, int overlap);
+    // overlap != 0 (only where accumulate_overlap_ok): launched one workgroup per CU short of full occupancy, wave
+    // priorities one level down, so that a wave of another MSM's tail kernels fits and wins on every SIMD
     // endo_points != null: list entries >= n_real name phi(P_(e - n_real)) = endo_points[e - n_real]
     // lanes of k_accumulate the device holds at once (CUs x resident workgroups x workgroup size)
-    size_t (*accumulate_resident_lanes)();
+    size_t (*accumulate_resident_lanes)(int overlap);
+    int accumulate_overlap_ok;   // the tail kernels of this group were built to fit beside an overlap-mode accumulation
     // closes the buckets that span several lanes; queue: fixup_queue_words(W*T) words, the
     // first two zeroed
     void (*accumulate_fixup)(hipStream_t, const uint32_t* ends, uint32_t* buckets, uint32_t* part_first,

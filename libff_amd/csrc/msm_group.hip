@@ -65,6 +65,15 @@ using FR = typename GP::fr;
 #ifndef AMDMSM_ACC_WAVES
 #define AMDMSM_ACC_WAVES 1
 #endif
+// Overlap mode (engine.cpp amdmsm_ctx::bulk_stream): AMDMSM_OVERLAP_OK marks a group whose tail kernels are built to
+// fit beside an accumulation that leaves one workgroup per CU free -- AMDMSM_TAIL_WAVES waves per SIMD as their
+// register budget (4 -> 128 VGPRs, what three accumulation waves of 128 leave of a SIMD's 512)
+#ifndef AMDMSM_OVERLAP_OK
+#define AMDMSM_OVERLAP_OK 0
+#endif
+#ifndef AMDMSM_TAIL_WAVES
+#define AMDMSM_TAIL_WAVES 1
+#endif
 template <int DEG, bool I> struct coord_sel;
 template <bool I> struct coord_sel<1, I> { using type = Fp<FQ, I>; };
 template <bool I> struct coord_sel<2, I> { using type = Fp2<FQ, GP::NR_SMALL == 0 ? -1 : GP::NR_SMALL, I>; };
@@ -990,18 +999,26 @@ __global__ void __launch_bounds__(TPB, AMDMSM_ACC_WAVES) k_accumulate(const uint
     // (only for launches of one or two rounds of resident waves -- sync_waves: in a long launch the
     // newcomers' high priority holds back the waves that are about to free their slots, 2^24 points:
     // 18.0 -> 18.8 ms, 2^26: 67.3 -> 68.8)
+    // (sync_waves == 2, overlap mode: one level down -- 2, 1, 0 -- so that the tail kernels of the MSM in front,
+    // which run at priority 3, win the SIMD whenever they have an instruction ready)
     const uint32_t span_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)S);
     const uint32_t mark1 = sync_waves ? span_u / 2 : 0xffffffffu, mark2 = sync_waves ? span_u - span_u / 8 : 0xffffffffu,
                    mark3 = sync_waves ? span_u - span_u / 16 : 0xffffffffu;
-    if (sync_waves) __builtin_amdgcn_s_setprio(3);
+    if (sync_waves == 1) __builtin_amdgcn_s_setprio(3);
+    if (sync_waves == 2) __builtin_amdgcn_s_setprio(2);
 #endif
     for (uint32_t k = lo; k < hi; ++k) {
 #if AMDMSM_ACC_PRIO
         {
             const uint32_t j = (uint32_t)__builtin_amdgcn_readfirstlane((int)(k - lo));
-            if (j == mark1) __builtin_amdgcn_s_setprio(2);
-            if (j == mark2) __builtin_amdgcn_s_setprio(1);
-            if (j == mark3) __builtin_amdgcn_s_setprio(0);
+            if (sync_waves == 1) {
+                if (j == mark1) __builtin_amdgcn_s_setprio(2);
+                if (j == mark2) __builtin_amdgcn_s_setprio(1);
+                if (j == mark3) __builtin_amdgcn_s_setprio(0);
+            } else {
+                if (j == mark1) __builtin_amdgcn_s_setprio(1);
+                if (j == mark2) __builtin_amdgcn_s_setprio(0);
+            }
         }
 #endif
         const uint32_t kk = (k - lo) & 15u;
@@ -1164,13 +1181,14 @@ __global__ void __launch_bounds__(64) k_accumulate_compact(const uint32_t* __res
 // G lanes per queued bucket (G = 64 for the long queue, MID_G for the mid queue): the lanes
 // stride over its partials (one per folded block, see k_accumulate_compact), XOR butterfly,
 // the group's first lane stores
-__global__ void __launch_bounds__(64) k_accumulate_fixup_queue(const uint32_t* __restrict__ ends,
+__global__ void __launch_bounds__(64, AMDMSM_TAIL_WAVES) k_accumulate_fixup_queue(const uint32_t* __restrict__ ends,
                                                                const uint32_t* __restrict__ part_first,
                                                                const uint32_t* __restrict__ part_last,
                                                                const uint32_t* __restrict__ cont_bucket,
                                                                uint32_t* __restrict__ buckets,
                                                                const uint32_t* __restrict__ queue, int mid, uint32_t G,
                                                                size_t lanes, uint32_t B, uint32_t S, uint32_t T) {
+    __builtin_amdgcn_s_setprio(3);
     const uint32_t count = queue[mid];
     const uint32_t* qb = queue + 2 + (mid ? 2 * fixup_queue_cap_long(lanes) : 0);
     // every field product costs a wave about a microsecond whatever its lane count, so with
@@ -1383,9 +1401,10 @@ __global__ void __launch_bounds__(SUMW_THREADS) k_sum_block_wide(const uint32_t*
 // Against k_reduce_segments this removes the (segment offset) x (segment sum) multiples -- 13 doublings
 // and up to 13 additions per lane at 2^20 points, two thirds of that kernel's field products -- and every
 // level is a plain sum.
-__global__ void __launch_bounds__(64) k_bucket_sums(const uint32_t* __restrict__ buckets, int W, uint32_t B, int h,
+__global__ void __launch_bounds__(64, AMDMSM_TAIL_WAVES) k_bucket_sums(const uint32_t* __restrict__ buckets, int W, uint32_t B, int h,
                                                     uint32_t q_row, uint32_t q_col, uint32_t row_blocks,
                                                     uint32_t* __restrict__ out) {
+    __builtin_amdgcn_s_setprio(3);   // beside another MSM's accumulation (overlap mode) the tail goes first
     const bool col = blockIdx.x >= row_blocks;
     const size_t t = ((size_t)(blockIdx.x - (col ? row_blocks : 0u)) * 64 + threadIdx.x) / RED_LANES;
     const uint32_t C = 1u << h, R = B >> h;
@@ -1419,6 +1438,7 @@ __global__ void __launch_bounds__(64) k_bucket_sums(const uint32_t* __restrict__
 __global__ void __launch_bounds__(256) k_plane_sums(const uint32_t* __restrict__ rc, int W, int c, int h,
                                                      uint32_t* __restrict__ planes) {
     __shared__ uint32_t part[4 * XYZW];
+    __builtin_amdgcn_s_setprio(3);
     const uint32_t w = blockIdx.x / (uint32_t)c, k = blockIdx.x % (uint32_t)c;
     const uint32_t C = 1u << h, R = (1u << (c - 1)) >> h, NP = R + 1 + C;
     const bool from_cols = k < (uint32_t)h;
@@ -1575,6 +1595,7 @@ AMDMSM_DEV void horner_chain(Jac<EE>& res, const uint32_t* __restrict__ window_s
 
 __global__ void __launch_bounds__(64) k_horner(const uint32_t* __restrict__ window_sums, int W, int c, int form,
                                                const uint32_t* __restrict__ init, uint32_t* __restrict__ out) {
+    __builtin_amdgcn_s_setprio(3);
     Jac<E> res;
     horner_chain(res, window_sums, W, c, init);
     if (threadIdx.x == 0) store_out(out, res, form);
@@ -1582,6 +1603,7 @@ __global__ void __launch_bounds__(64) k_horner(const uint32_t* __restrict__ wind
 
 // window sum = sum_k 2^k planes[w][k]: the Horner chain with ONE doubling between planes, one wave per window
 __global__ void __launch_bounds__(64) k_window_horner(const uint32_t* __restrict__ planes, int c, uint32_t* __restrict__ out) {
+    __builtin_amdgcn_s_setprio(3);
     Jac<E> res;
     horner_chain(res, planes + (size_t)blockIdx.x * c * XYZW, c, 1, nullptr);
     if (threadIdx.x == 0) store_jac(out + (size_t)blockIdx.x * XYZW, res);
@@ -2238,11 +2260,17 @@ void l_sort(hipStream_t st, const uint32_t* scalars, size_t n, int mont, int c, 
     hipLaunchKernelGGL(k_sort_big_scatter, dim3(2048), dim3(SORT_TPB), big_lds, st, tmp_payload, tmp_key16, coarse, stride, c,
                        hb, sg.big_cap, big, lists);
 }
-size_t l_accumulate_resident_lanes();
+size_t l_accumulate_resident_lanes(int overlap);
+// dynamic LDS that keeps one workgroup per CU out in overlap mode: with k workgroups resident by registers the
+// kernel's 16 KiB of staging plus this must exceed 160 KiB / k
+constexpr size_t ACC_OVERLAP_LDS = AMDMSM_ACC_WAVES >= 3 ? (160 * 1024) / AMDMSM_ACC_WAVES - 16 * 1024 + 1024 : 0;
 void l_accumulate(hipStream_t st, const uint32_t* ends, const uint32_t* lists, size_t list_stride, const uint32_t* bases,
                   uint32_t* buckets, uint32_t* part_first, uint32_t* part_last, uint32_t* cont_bucket, int W, uint32_t B,
-                  uint32_t S, uint32_t T, const uint32_t* endo_pts, size_t n_real) {
-    const int sync_waves = (size_t)W * T * ACC_LANES <= 2 * l_accumulate_resident_lanes() * ACC_LANES ? 1 : 0;
+                  uint32_t S, uint32_t T, const uint32_t* endo_pts, size_t n_real, int overlap) {
+    overlap = overlap && AMDMSM_OVERLAP_OK && ACC_OVERLAP_LDS;
+    int sync_waves = (size_t)W * T * ACC_LANES <= 2 * l_accumulate_resident_lanes(overlap) * ACC_LANES ? 1 : 0;
+    if (overlap) sync_waves = 2;   // also in long launches: the tail waves of the MSM in front must win the SIMD
+    const size_t dyn_lds = overlap ? ACC_OVERLAP_LDS : 0;
 #ifdef AMDMSM_ACC_TRACE
     {
         const size_t waves = (size_t)blocks_for((size_t)W * T * ACC_LANES) * TPB / 64;
@@ -2254,7 +2282,7 @@ void l_accumulate(hipStream_t st, const uint32_t* ends, const uint32_t* lists, s
             cap = waves;
         }
         (void)hipMemsetAsync(d_trace, 0, waves * 24, st);
-        hipLaunchKernelGGL(k_accumulate, dim3(blocks_for((size_t)W * T * ACC_LANES)), dim3(TPB), 0, st, ends, lists,
+        hipLaunchKernelGGL(k_accumulate, dim3(blocks_for((size_t)W * T * ACC_LANES)), dim3(TPB), dyn_lds, st, ends, lists,
                            list_stride, bases, buckets, part_first, part_last, cont_bucket, W, B, S, T, endo_pts,
                            endo_pts ? (uint32_t)n_real : 0x80000000u, sync_waves, d_trace);
         if (const char* path = getenv("AMDMSM_ACC_TRACE_FILE")) {
@@ -2268,8 +2296,8 @@ void l_accumulate(hipStream_t st, const uint32_t* ends, const uint32_t* lists, s
         }
     }
 #else
-    hipLaunchKernelGGL(k_accumulate, dim3(blocks_for((size_t)W * T * ACC_LANES)), dim3(TPB), 0, st, ends, lists, list_stride,
-                       bases, buckets, part_first, part_last, cont_bucket, W, B, S, T, endo_pts,
+    hipLaunchKernelGGL(k_accumulate, dim3(blocks_for((size_t)W * T * ACC_LANES)), dim3(TPB), dyn_lds, st, ends, lists,
+                       list_stride, bases, buckets, part_first, part_last, cont_bucket, W, B, S, T, endo_pts,
                        endo_pts ? (uint32_t)n_real : 0x80000000u, sync_waves);
 #endif
 }
@@ -2281,14 +2309,16 @@ void l_glv_digits(hipStream_t st, const uint32_t* scalars, size_t n, int mont, i
     if (!n) return;
     hipLaunchKernelGGL(k_glv_digits, dim3(blocks_for(n)), dim3(TPB), 0, st, scalars, n, mont, c, W, out);
 }
-size_t l_accumulate_resident_lanes() {
-    static const size_t lanes = [] {
+size_t l_accumulate_resident_lanes(int overlap) {
+    auto query = [](size_t dyn_lds) {
         int dev = 0, cus = 256, blocks = 0;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_accumulate, TPB, 0) != hipSuccess || blocks <= 0) blocks = 4;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_accumulate, TPB, dyn_lds) != hipSuccess || blocks <= 0) blocks = 4;
         return (size_t)cus * (size_t)blocks * TPB / ACC_LANES;
-    }();
-    return lanes;
+    };
+    static const size_t lanes = query(0);
+    static const size_t lanes_overlap = (AMDMSM_OVERLAP_OK && ACC_OVERLAP_LDS) ? query(ACC_OVERLAP_LDS) : lanes;
+    return overlap ? lanes_overlap : lanes;
 }
 void l_accumulate_fixup(hipStream_t st, const uint32_t* ends, uint32_t* buckets, uint32_t* part_first,
                         const uint32_t* part_last, const uint32_t* cont_bucket, uint32_t* queue, int W, uint32_t B,
@@ -2442,7 +2472,7 @@ void l_madd_bench(hipStream_t st, const uint32_t* pts, uint32_t* out, size_t nth
 const group_vtable g_vt = {
     GP::CURVE, GP::GROUP, FRW, EW, FQ::N, FR::BITS, GP::LIBFF_PROJECTIVE ? 1 : 0, (int)RED_FOLD, FR::R,
     GLV::BOUND_LOG2_X1000, GP::SUBGROUP_CHECK == 0 ? 1 : 0, GLV::LAMBDA, l_endo_points, l_glv_digits,
-    l_import_bases, l_precompute_table, l_count, l_scatter, l_scalar_stats, l_sort, l_accumulate, l_accumulate_resident_lanes, l_accumulate_fixup, l_reduce_segments, l_sum_butterfly, l_sum_block, l_reduce_rowcol, l_horner, l_sum_points,
+    l_import_bases, l_precompute_table, l_count, l_scatter, l_scalar_stats, l_sort, l_accumulate, l_accumulate_resident_lanes, (AMDMSM_OVERLAP_OK && ACC_OVERLAP_LDS) ? 1 : 0, l_accumulate_fixup, l_reduce_segments, l_sum_butterfly, l_sum_block, l_reduce_rowcol, l_horner, l_sum_points,
     l_gen_bases_seq, l_export_affine, l_ffi_decode_points, l_ffi_decode_scalars, l_ffi_encode_point, l_disk_decode, l_disk_decode_compressed, l_fixed_base_exp, l_field_op, l_group_op, l_digits, l_mul_bench, l_madd_bench,
 };
 
