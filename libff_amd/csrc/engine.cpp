@@ -511,10 +511,13 @@ int msm_device_impl(amdmsm_ctx *ctx, const group_vtable *vt, const uint32_t *d_b
     // tuning knobs for experiments: AMDMSM_ACC_S (entries per accumulation lane)
     static const int acc_s_env = getenv("AMDMSM_ACC_S") ? atoi(getenv("AMDMSM_ACC_S")) : 0;
     static const int groups_env = getenv("AMDMSM_WINDOW_GROUPS") ? atoi(getenv("AMDMSM_WINDOW_GROUPS")) : 0;
-    // overlap mode (several MSMs in flight, see amdmsm_ctx::bulk_stream); AMDMSM_OVERLAP=0 leaves the ordering of
-    // concurrent MSMs to the hardware queues as before
-    static const bool overlap_env = !(getenv("AMDMSM_OVERLAP") && atoi(getenv("AMDMSM_OVERLAP")) == 0);
-    const bool overlap = overlap_env && ctx->depth > 1 && vt->accumulate_overlap_ok && !groups_env;
+    // overlap mode (several MSMs in flight, see amdmsm_ctx::bulk_stream): built and parity-tested, but OFF unless
+    // AMDMSM_OVERLAP=1 -- measured on MI355X / ROCm 7.2 it loses (2^20, three in flight: 2.35 - 2.69 ms per MSM against
+    // 2.09 - 2.14 with the ordering left to the hardware queues and 2.19 one at a time): the kernel traces in
+    // profiles/r03_pipelined_*.txt show the intended schedule (sort and accumulation of MSM k+1 under the tail of MSM k)
+    // but every kernel behind a cross-queue event wait starts ~50 us late, which outweighs the 0.7 ms tail it hides.
+    static const bool overlap_env = getenv("AMDMSM_OVERLAP") && atoi(getenv("AMDMSM_OVERLAP")) != 0;
+    const bool overlap = overlap_env && ctx->depth > 1 && ctx->bulk_stream && vt->accumulate_overlap_ok && !groups_env;
     int rc = make_plan(vt, entries, opts ? opts->window_bits : 0, opts ? opts->segment_len : 0, p, acc_s_env, table_digits,
                        groups_env, glv, overlap);
     if (rc) return fail(ctx, rc, "bad window_bits / segment_len");
@@ -562,18 +565,22 @@ int msm_device_impl(amdmsm_ctx *ctx, const group_vtable *vt, const uint32_t *d_b
     // (measured at 2^20 points: beside the whole sort 0.29 ms for the phase, beside its LDS-bound
     // second half only 0.35, after it 0.30; the plain path's sort takes 0.24)
     // enqueued after the sort kernels, ordered only behind the start of the call
-    HIP_TRY(ctx, hipStreamWaitEvent(sl.side[0], sl.tail_done[0], 0));
-    HIP_TRY(ctx, hipMemsetAsync(buckets, 0, (size_t)p.W * p.B * vt->el_words * 16, sl.side[0]));
-    for (int g = 0; g < p.G; ++g) HIP_TRY(ctx, hipMemsetAsync(ws + p.off_queue + g * p.queue_stride, 0, 8, sl.side[0]));
-    if (endo_beside) vt->endo_points(sl.side[0], d_bases, n, (uint32_t *)(ws + p.off_endo));
-    HIP_TRY(ctx, hipEventRecord(sl.acc_done[0], sl.side[0]));
+    // (overlap mode keeps them on the bulk stream: the runtime multiplexes the many streams of a process over a few
+    // hardware queues, and a side stream that lands in the queue of a caller's stream sits behind that stream's wait
+    // for the previous MSM's tail -- seen in a kernel trace: the accumulation then started only after that tail)
+    hipStream_t side = overlap ? st : sl.side[0];
+    if (!overlap) HIP_TRY(ctx, hipStreamWaitEvent(side, sl.tail_done[0], 0));
+    HIP_TRY(ctx, hipMemsetAsync(buckets, 0, (size_t)p.W * p.B * vt->el_words * 16, side));
+    for (int g = 0; g < p.G; ++g) HIP_TRY(ctx, hipMemsetAsync(ws + p.off_queue + g * p.queue_stride, 0, 8, side));
+    if (endo_beside) vt->endo_points(side, d_bases, n, (uint32_t *)(ws + p.off_endo));
+    if (!overlap) HIP_TRY(ctx, hipEventRecord(sl.acc_done[0], side));
     if (hook && hook->fn) {
         hipEvent_t wait_for = nullptr;
         rc = hook->fn(hook->arg, &wait_for);
         if (rc) return rc;
         if (wait_for) HIP_TRY(ctx, hipStreamWaitEvent(st, wait_for, 0));
     }
-    HIP_TRY(ctx, hipStreamWaitEvent(st, sl.acc_done[0], 0));
+    if (!overlap) HIP_TRY(ctx, hipStreamWaitEvent(st, sl.acc_done[0], 0));
     if (glv && !d_endo_resident && !endo_beside) vt->endo_points(st, d_bases, n, (uint32_t *)(ws + p.off_endo));
     const size_t zzw = (size_t)vt->el_words * 4, xyzw = (size_t)vt->el_words * 3;   // words per XYZZ / Jacobian point
     const size_t M0 = p.B / p.L, cap1 = M0 / 2 + 1;
@@ -757,15 +764,6 @@ int amdmsm_ctx_create(int device, amdmsm_ctx **out) {
             return AMDMSM_ERR_HIP;
         }
     }
-    {
-        int least = 0, greatest = 0;
-        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-        if (hipStreamCreateWithPriority(&ctx->bulk_stream, hipStreamNonBlocking, least) != hipSuccess ||
-            hipStreamCreateWithPriority(&ctx->tail_stream, hipStreamNonBlocking, greatest) != hipSuccess) {
-            delete ctx;
-            return AMDMSM_ERR_HIP;
-        }
-    }
     for (auto &sl : ctx->slots) {
         bool ok = hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) == hipSuccess;
         for (hipEvent_t *e : {&sl.ov_in, &sl.ov_acc, &sl.ov_tail}) ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
@@ -888,6 +886,30 @@ int amdmsm_set_pipeline_depth(amdmsm_ctx *ctx, int depth) {
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     dev_guard g(ctx->device);
     HIP_TRY(ctx, hipDeviceSynchronize());
+    static const bool overlap_wanted = getenv("AMDMSM_OVERLAP") && atoi(getenv("AMDMSM_OVERLAP")) != 0;
+    if (depth > 1 && overlap_wanted && !ctx->bulk_stream) {
+        // overlap mode's two streams, created when first needed.
+        // Both streams need hardware queues of their own: the runtime multiplexes a process's streams over a few
+        // hardware queues, and a stream that shares one with a caller's stream sits behind that stream's barrier
+        // packets (its wait for the previous MSM's tail) -- seen in kernel traces as a bulk part that starts only after
+        // that tail.  Streams created with a CU mask get a dedicated queue (the mask is a queue property); the mask
+        // here names every CU.  AMDMSM_STREAM_KIND: 0 plain streams, 1 tails on a high-priority stream, 2 (default)
+        // full-CU-mask streams, 3 both high priority (experiments, profiles/r03_experiments.txt).
+        static const int kind = getenv("AMDMSM_STREAM_KIND") ? atoi(getenv("AMDMSM_STREAM_KIND")) : 2;
+        int least = 0, greatest = 0;
+        HIP_TRY(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
+        if (kind == 2) {
+            int cus = 256;
+            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+            std::vector<uint32_t> mask((size_t)(cus + 31) / 32, 0xffffffffu);
+            if (cus % 32) mask.back() = (1u << (cus % 32)) - 1u;
+            HIP_TRY(ctx, hipExtStreamCreateWithCUMask(&ctx->bulk_stream, (uint32_t)mask.size(), mask.data()));
+            HIP_TRY(ctx, hipExtStreamCreateWithCUMask(&ctx->tail_stream, (uint32_t)mask.size(), mask.data()));
+        } else {
+            HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->bulk_stream, hipStreamNonBlocking, kind == 3 ? greatest : 0));
+            HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->tail_stream, hipStreamNonBlocking, kind == 0 ? 0 : greatest));
+        }
+    }
     ctx->depth = depth;
     ctx->next = 0;
     return AMDMSM_OK;

@@ -1468,6 +1468,48 @@ __global__ void __launch_bounds__(256) k_plane_sums(const uint32_t* __restrict__
     if (lane < (uint32_t)RED_LANES) store_jac(planes + ((size_t)w * c + k) * XYZW, p);
 }
 
+// The same with the last levels on lane-split elements (as k_sum_block_wide): every reduction lane adds its
+// strided share of the plane's inputs, groups of four lanes fold per lane (two levels), the partial sums go to
+// LDS and the waves of the workgroup halve them round by round, one lane-split addition at a time.
+__global__ void __launch_bounds__(SUMW_THREADS) k_plane_sums_wide(const uint32_t* __restrict__ rc, int W, int c, int h,
+                                                                  uint32_t* __restrict__ planes) {
+    __shared__ uint32_t buf[2][SUMW_SLOTS * XYZW];
+    __builtin_amdgcn_s_setprio(3);
+    const uint32_t w = blockIdx.x / (uint32_t)c, k = blockIdx.x % (uint32_t)c;
+    const uint32_t C = 1u << h, R = (1u << (c - 1)) >> h, NP = R + 1 + C;
+    const bool from_cols = k < (uint32_t)h;
+    const uint32_t* src = rc + ((size_t)w * NP + (from_cols ? R + 1 : 0)) * XYZW;
+    const uint32_t bit = from_cols ? k : k - (uint32_t)h;
+    const bool top = k == (uint32_t)c - 1;
+    const uint32_t M = top ? 1u : (from_cols ? C : R) / 2;
+    constexpr uint32_t NLANES = SUMW_THREADS / RED_LANES, NWAVES = SUMW_THREADS / 64;
+    const uint32_t i0 = threadIdx.x / RED_LANES, wave = threadIdx.x >> 6;
+    Jac<ER> p, x;
+    jac_set_inf(p);
+    for (uint32_t i = i0; i < M; i += NLANES) {
+        const uint32_t idx = top ? R : (((i >> bit) << (bit + 1)) | (1u << bit) | (i & ((1u << bit) - 1u)));
+        load_jac(x, src + (size_t)idx * XYZW);
+        jac_add(p, p, x);
+    }
+    wave_group_sum_r(p, 4);
+    if ((i0 & 3u) == 0) store_jac(buf[0] + (size_t)(i0 >> 2) * XYZW, p);
+    __syncthreads();
+    const WideEnv<FQ> env = wide_env<FQ>();
+    uint32_t K = ((M < NLANES ? M : NLANES) + 3) / 4;   // partial sums: a power of two, or 1
+    int cur = 0;
+    while (K > 1) {
+        const uint32_t pairs = K / 2;
+        for (uint32_t q = wave; q < pairs; q += NWAVES) {   // wave-uniform
+            const uint32_t* a = buf[cur] + (size_t)(2 * q) * XYZW;
+            sum_wide_add(env, a, a + XYZW, buf[cur ^ 1] + (size_t)q * XYZW);
+        }
+        __syncthreads();
+        cur ^= 1;
+        K = pairs;
+    }
+    for (uint32_t t = threadIdx.x; t < (uint32_t)XYZW; t += SUMW_THREADS) planes[((size_t)w * c + k) * XYZW + t] = buf[cur][t];
+}
+
 // Horner over the window sums, high to low, c doublings between windows (multiexp.tcc:612-629),
 // by one wave.  Prime-field groups with N < 16 limbs run the whole chain on lane-split
 // coordinates (wide.cuh: one limb per lane, four products per step in the four DPP rows, ~3x
@@ -1601,11 +1643,24 @@ __global__ void __launch_bounds__(64) k_horner(const uint32_t* __restrict__ wind
     if (threadIdx.x == 0) store_out(out, res, form);
 }
 
-// window sum = sum_k 2^k planes[w][k]: the Horner chain with ONE doubling between planes, one wave per window
-__global__ void __launch_bounds__(64) k_window_horner(const uint32_t* __restrict__ planes, int c, uint32_t* __restrict__ out) {
+// window sum = sum_k 2^k planes[w][k].  One workgroup per window: wave j folds planes 4j .. 4j+3 (Horner with one
+// doubling between planes), then the first wave folds the ceil(c / 4) group values with four doublings between
+// them -- a dependent chain of 3 + ceil(c / 4) additions instead of c - 1.
+constexpr int WH_MAX_GROUPS = 6;   // c <= 24
+__global__ void __launch_bounds__(64 * WH_MAX_GROUPS) k_window_horner(const uint32_t* __restrict__ planes, int c,
+                                                                       uint32_t* __restrict__ out) {
+    __shared__ uint32_t grp[WH_MAX_GROUPS * XYZW];
     __builtin_amdgcn_s_setprio(3);
+    const int wave = (int)(threadIdx.x >> 6), ng = (c + 3) / 4;
     Jac<E> res;
-    horner_chain(res, planes + (size_t)blockIdx.x * c * XYZW, c, 1, nullptr);
+    if (wave < ng) {
+        const int k0 = 4 * wave, cnt = (c - k0 < 4) ? c - k0 : 4;
+        horner_chain(res, planes + ((size_t)blockIdx.x * c + k0) * XYZW, cnt, 1, nullptr);
+        if ((threadIdx.x & 63u) == 0) store_jac(grp + wave * XYZW, res);
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    horner_chain(res, grp, ng, 4, nullptr);
     if (threadIdx.x == 0) store_jac(out + (size_t)blockIdx.x * XYZW, res);
 }
 
@@ -2369,10 +2424,15 @@ void l_reduce_rowcol(hipStream_t st, const uint32_t* buckets, int W, uint32_t B,
     const unsigned row_blocks = blocks_for(row_lanes, 64), col_blocks = blocks_for(col_lanes, 64);
     hipLaunchKernelGGL(k_bucket_sums, dim3(row_blocks + col_blocks), dim3(64), 0, st, buckets, W, B, h, q_row, q_col, row_blocks, rc);
     const uint32_t maxm = (C > R ? C : R) / 2;
-    unsigned threads = (unsigned)((maxm * RED_LANES + 63) / 64 * 64);
-    threads = threads < 64 ? 64 : (threads > 256 ? 256 : threads);
-    hipLaunchKernelGGL(k_plane_sums, dim3((unsigned)(W * c)), dim3(threads), 0, st, rc, W, c, h, planes);
-    hipLaunchKernelGGL(k_window_horner, dim3((unsigned)W), dim3(64), 0, st, planes, c, out);
+    static const bool wide_planes = !(getenv("AMDMSM_PLANES_WIDE") && atoi(getenv("AMDMSM_PLANES_WIDE")) == 0);
+    if (maxm >= 8 && wide_planes) {
+        hipLaunchKernelGGL(k_plane_sums_wide, dim3((unsigned)(W * c)), dim3(SUMW_THREADS), 0, st, rc, W, c, h, planes);
+    } else {
+        unsigned threads = (unsigned)((maxm * RED_LANES + 63) / 64 * 64);
+        threads = threads < 64 ? 64 : (threads > 256 ? 256 : threads);
+        hipLaunchKernelGGL(k_plane_sums, dim3((unsigned)(W * c)), dim3(threads), 0, st, rc, W, c, h, planes);
+    }
+    hipLaunchKernelGGL(k_window_horner, dim3((unsigned)W), dim3((unsigned)(64 * ((c + 3) / 4))), 0, st, planes, c, out);
 }
 void l_horner(hipStream_t st, const uint32_t* window_sums, int W, int c, int form, const uint32_t* init, uint32_t* out) {
     hipLaunchKernelGGL(k_horner, dim3(1), dim3(64), 0, st, window_sums, W, c, form, init, out);
