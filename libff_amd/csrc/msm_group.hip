@@ -2091,11 +2091,53 @@ struct endo_check<G, 2> {
 template <class G>
 AMDMSM_DEV bool endo_subgroup_check(const Aff<E>& a) { return endo_check<G>::run(a); }
 
+// [a]P + [b]phi(P) == 0 with (a, b) = glv::SUB_*: a + b lambda = 0 (mod r) and a^2 - a b + b^2 = r, so for a curve
+// point the test holds exactly when [r]P == 0 (tools/gen_params.py subgroup_vector) -- the reference's
+// zero() == scalar_field::mod * P (bw6_761_g1.cpp:385-388, alt_bn128_g2.cpp:389-392, and bls12_377_g2.cpp:461-473 as
+// decided on this curve) with scalars of half the length: one joint double-and-add over the non-adjacent forms of a
+// and b (about 2/3 of a mixed addition per doubling instead of a full addition every second doubling of a scalar
+// twice as long).  Every lane follows the same digits: no divergence.
+template <bool I>
+AMDMSM_DEV void scale_by_beta(Fp<FQ, I>& x) {
+    Fp<FQ, I> beta;
+#pragma unroll
+    for (int j = 0; j < FQ::N; ++j) beta.v[j] = GP::GLV_BETA[j];
+    fp_mul(x, x, beta);
+}
+template <int NR, bool I>
+AMDMSM_DEV void scale_by_beta(Fp2<FQ, NR, I>& x) {   // beta lies in Fq: both components are scaled
+    scale_by_beta(x.c0);
+    scale_by_beta(x.c1);
+}
+AMDMSM_DEV bool lattice_subgroup_check(const Aff<E>& a) {
+    Aff<E> p1 = a, p2 = a, n1, n2;
+    scale_by_beta(p2.x);   // phi(x, y) = (beta x, y)
+    n1 = p1;
+    n2 = p2;
+    el_neg(n1.y, n1.y);
+    el_neg(n2.y, n2.y);
+    Jac<E> t;
+    jac_set_inf(t);
+    for (int i = GLV::SUB_BITS - 1; i >= 0; --i) {
+        jac_dbl(t, t);
+        const int wd = i >> 5;
+        const uint32_t m = 1u << (i & 31);
+        if (GLV::SUB_A_POS[wd] & m) jac_madd(t, p1);
+        if (GLV::SUB_A_NEG[wd] & m) jac_madd(t, n1);
+        if (GLV::SUB_B_POS[wd] & m) jac_madd(t, p2);
+        if (GLV::SUB_B_NEG[wd] & m) jac_madd(t, n2);
+    }
+    return jac_is_inf(t);
+}
+
 AMDMSM_DEV bool in_safe_subgroup(const Aff<E>& a) {
     if (GP::SUBGROUP_CHECK == 0) return true;   // alt_bn128_g1.cpp:359-363
+#ifndef AMDMSM_SUBGROUP_BY_ORDER
+    if (GP::SUBGROUP_CHECK == 3) return lattice_subgroup_check(a);
+#endif
     Jac<E> p, t;
     jac_from_aff(p, a);
-    if (GP::SUBGROUP_CHECK == 1) {               // zero() == scalar_field::mod * P (bw6_761_g1.cpp:385-388)
+    if (GP::SUBGROUP_CHECK == 1 || GP::SUBGROUP_CHECK == 3) {   // zero() == scalar_field::mod * P (bw6_761_g1.cpp:385-388)
         jac_mul_words<E, FRW>(t, p, FR::P);
         return jac_is_inf(t);
     }

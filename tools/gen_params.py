@@ -269,7 +269,35 @@ def glv_params(cname):
         match = [beta for beta in cube_roots_of_unity(q) if Q == (tuple(v * beta % q for v in P[0]), P[1])]
         assert len(match) == 1, (cname, gname)
         betas[gname] = match[0]
-    return dict(lam=lam, s=s, G=G, M=M, bound=bound, hw=hw, gw=gw, cw=gw - 1, betas=betas, frw=frw)
+    return dict(lam=lam, s=s, G=G, M=M, bound=bound, hw=hw, gw=gw, cw=gw - 1, betas=betas, frw=frw,
+                sub=subgroup_vector(r, lam, (a1, b1), (a2, b2)))
+
+
+def subgroup_vector(r, lam, v1, v2):
+    """(a, b) with a + b lam = 0 (mod r) and norm a^2 - a b + b^2 = r exactly: the generator of the prime ideal of
+    Z[w] above r that the lattice is.  For a curve point P, (a + b phi)P = 0 implies (a + b phi^2)(a + b phi)P = [r]P = 0,
+    and on the order-r subgroup phi = [lam], so [a]P + [b]phi(P) == 0 <=> [r]P == 0 -- the reference's
+    is_in_safe_subgroup (bw6_761_g1.cpp:385-388, alt_bn128_g2.cpp:389-392) at half the scalar length."""
+    for i in range(-3, 4):
+        for j in range(-3, 4):
+            a, b = i * v1[0] + j * v2[0], i * v1[1] + j * v2[1]
+            if (i or j) and a * a - a * b + b * b == r and (a + b * lam) % r == 0:
+                return a, b
+    raise AssertionError("no lattice vector of norm r")
+
+
+def naf(v):
+    """non-adjacent form, least significant digit first"""
+    d = []
+    while v:
+        if v & 1:
+            x = 2 - (v % 4)
+            v -= x
+        else:
+            x = 0
+        d.append(x)
+        v //= 2
+    return d
 
 
 def glv_split(gp, k):
@@ -348,6 +376,20 @@ def emit_device_header():
         w(f"    static constexpr uint32_t M[4][{hc}] = {{" +
           ", ".join(c_arr(limbs(v % (1 << (32 * hc)), hc, 32), "0x%08xu") for v in rows) + "};")
         w(f"    static constexpr uint32_t LAMBDA[{gp['frw']}] = {c_arr(limbs(gp['lam'], gp['frw'], 32), '0x%08xu')};   // plain integer")
+        # subgroup test [a]P + [b]phi(P) == 0 (subgroup_vector): non-adjacent forms of a and b as bit masks
+        sa, sb = gp["sub"]
+        nb = max(len(naf(sa)), len(naf(sb)))
+        nw = (nb + 31) // 32
+        w(f"    // a + b LAMBDA = 0 (mod r), a^2 - a b + b^2 = r: [a]P + [b]phi(P) == 0  <=>  [r]P == 0 on the curve")
+        w(f"    static constexpr int SUB_BITS = {nb};   // digits of the non-adjacent forms below")
+        w(f"    static constexpr int SUB_W = {nw};")
+        for nm, v in (("A", sa), ("B", sb)):
+            d = naf(v)
+            pos = sum(1 << i for i, x in enumerate(d) if x == 1)
+            neg = sum(1 << i for i, x in enumerate(d) if x == -1)
+            assert pos - neg == v
+            w(f"    static constexpr uint32_t SUB_{nm}_POS[{nw}] = {c_arr(limbs(pos, nw, 32), '0x%08xu')};")
+            w(f"    static constexpr uint32_t SUB_{nm}_NEG[{nw}] = {c_arr(limbs(neg, nw, 32), '0x%08xu')};")
         w("};")
         w("")
     for cname, c in CURVES.items():
@@ -371,8 +413,8 @@ def emit_device_header():
               "  // libff in-memory coords are homogeneous projective")
             w(f"    static constexpr int NR_SMALL = {g.get('nr', 0)};     // Fq2 = Fq[u]/(u^2 - NR); 0 when DEG == 1")
             sub = g.get("subgroup", "order")
-            w(f"    static constexpr int SUBGROUP_CHECK = {dict(none=0, order=1, endo=2)[sub]};   "
-              "// 0 none, 1 [r]P == 0, 2 P + [c1]sigma(P) == 0")
+            w(f"    static constexpr int SUBGROUP_CHECK = {dict(none=0, order=3, endo=2)[sub]};   "
+              "// 0 none, 1 [r]P == 0, 2 P + [c1]sigma(P) == 0, 3 [a]P + [b]phi(P) == 0 (glv::SUB_*; equivalent to 1)")
             if sub == "endo":
                 w(f"    static constexpr uint32_t ENDO_BETA[{n}] = "
                   f"{c_arr(limbs(g['beta'] * fq['R'] % c['q'], n, 32), '0x%08xu')};")
