@@ -85,6 +85,8 @@ def parse_args():
     ap.add_argument("--precomputed-c", type=int, default=16,
                     help="N = 1: also time the precomputed-multiples MSM (multi_exp_stream_with_precompute's algorithm "
                          "on an HBM-resident table of [2^(jc)]P) with this window size; 0 disables")
+    ap.add_argument("--no-next-rows", action="store_true",
+                    help="N = 1: skip the batch_exp / multi_exp_stream / FFI legs (SURVEY.md section 8(f) rows)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="N = 1: skip the configs[2] / configs[4] legs (bls12_377 G1 2^22; bw6_761 G1 + bls12_377 G2 at 2^21 and 2^24)")
     ap.add_argument("--config4-log2n", type=int, default=24, help="N > 1: total points of the configs[4] leg; 0 disables")
@@ -408,6 +410,80 @@ def other_config_legs(args, tm, dev, device_index):
     return legs
 
 
+def next_row_legs(args, eng, dev):
+    """SURVEY.md section 8(f) rows through the same C ABI, one figure each (tools/bench_next.py has the long form with
+    the reference beside it): fixed-base batch_exp, multi_exp_stream from a file, the FFI entry with its validation."""
+    import ctypes
+    import tempfile
+
+    legs = {}
+    curve, group = 0, 1
+    sz = libff_amd.sizes(curve, group)
+    n = 1 << 20
+    # batch_exp / get_window_table (multiexp.tcc:809-947), window 17 = alt_bn128_G1::fixed_base_exp_window_table at 2^20
+    g = eng.gen_bases_seq(curve, group, 1, first=0)[0]
+    v = np.ascontiguousarray(random_scalars(curve, n, dev, 77).cpu().numpy()).view(np.uint64)
+    eng.batch_exp(curve, group, sz["fr_bits"], 17, g, v)
+    first = eng.batch_exp_timings()
+    t0 = time.perf_counter()
+    eng.batch_exp(curve, group, sz["fr_bits"], 17, g, v)
+    dt = time.perf_counter() - t0
+    again = eng.batch_exp_timings()
+    legs["batch_exp"] = {"workload": "alt_bn128 G1 batch_exp, 2^20 scalars, window 17 (15 x 2^17-entry table), host vectors in and out",
+                         "value": n / dt, "unit": "exponentiations/s", "ms_per_call": dt * 1e3,
+                         "device_ms": {"window_table_first_call": first["table_ms"], "exponentiations": again["exp_ms"],
+                                       "scalars_h2d": again["h2d_ms"], "results_d2h": again["d2h_ms"]},
+                         "exponentiations_per_s_device": n / (again["exp_ms"] * 1e-3)}
+    # multi_exp_stream (multiexp_stream.tcc:164-191): 2^20 on-disk records (binary, Montgomery, uncompressed) from the page cache
+    aff = torch.from_numpy(eng.gen_bases_seq(curve, group, n, first=0)[:, : sz["affine_bytes"] // 8].astype(np.int64)).contiguous()
+    cl = sz["affine_bytes"] // 16
+    rec = aff.view(n, 2, cl).flip(2).contiguous().view(torch.uint8).view(n, 2, cl, 8).flip(3).contiguous()   # big-endian coordinates
+    with tempfile.NamedTemporaryFile(dir=os.environ.get("TMPDIR", "/tmp"), suffix=".bases", delete=False) as f:
+        f.write(rec.numpy().tobytes())
+        path = f.name
+    eng.multi_exp_stream_file(curve, group, path, v)
+    t0 = time.perf_counter()
+    eng.multi_exp_stream_file(curve, group, path, v)
+    dt = time.perf_counter() - t0
+    os.unlink(path)
+    legs["multi_exp_stream_file"] = {"workload": "alt_bn128 G1 multi_exp_stream, 2^20 records of 64 B read from a file (page cache), "
+                                                 "scalars from host memory", "value": n / dt, "unit": "scalar-muls/s",
+                                     "ms_per_call": dt * 1e3, "file_GB_per_s": n * sz["affine_bytes"] / dt / 1e9}
+    # <curve>_g1_multiexp (include/libff_amd_ffi.h): big-endian plain inputs, every element validated on the device
+    for cname, cv, m in (("bls12_377", 1, 1 << 20), ("bw6_761", 2, 1 << 17)):
+        s1 = libff_amd.sizes(cv, 1)
+        fl = s1["affine_bytes"] // 16
+        am = np.ascontiguousarray(eng.gen_bases_seq(cv, 1, m, first=5)[:, : 2 * fl]).reshape(2 * m, fl)
+        one = np.zeros_like(am)
+        one[:, 0] = 1
+        plain = eng.field_op(cv, 1, 0, am, one)                       # x * 1 * R^-1: out of Montgomery form
+        bb = np.ascontiguousarray(np.ascontiguousarray(plain[:, ::-1]).view(np.uint8).reshape(2 * m, fl, 8)[..., ::-1]).reshape(-1)
+        sp = np.ascontiguousarray(random_scalars(cv, m, dev, 78).cpu().numpy()).view(np.uint64)   # read as plain integers < r
+        sb = np.ascontiguousarray(np.ascontiguousarray(sp[:, ::-1]).view(np.uint8).reshape(m, -1, 8)[..., ::-1]).reshape(-1)
+        o = np.zeros(s1["affine_bytes"], dtype=np.uint8)
+        fn = getattr(eng.lib, f"{cname}_g1_multiexp")
+        fn.restype = ctypes.c_bool
+        eng.lib.amdmsm_ffi_last_timings.restype = ctypes.c_bool
+
+        def call():
+            t0 = time.perf_counter()
+            ok = fn(bb.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(bb.size), sb.ctypes.data_as(ctypes.c_void_p),
+                    ctypes.c_size_t(sb.size), o.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(o.size))
+            return bool(ok), time.perf_counter() - t0
+
+        ok, _ = call()
+        ok2, dt = call()
+        ms = (ctypes.c_float * 3)()
+        if not (ok and ok2 and eng.lib.amdmsm_ffi_last_timings(ms)):
+            legs[f"ffi_{cname}_g1_multiexp"] = {"value": None, "note": "call failed"}
+            continue
+        legs[f"ffi_{cname}_g1_multiexp"] = {
+            "workload": f"{cname}_g1_multiexp, {m} big-endian plain (point, scalar) pairs from host memory, every point checked "
+                        "(range, curve equation, subgroup) on the device before the MSM", "value": m / dt, "unit": "scalar-muls/s",
+            "ms_per_call": dt * 1e3, "device_ms": {"inputs_h2d": ms[0], "decode_and_validate": ms[1], "msm_and_encode": ms[2]}}
+    return legs
+
+
 def single_gpu(args, tm, eng, dev, curve, group):
     log2n = args.log2n or 20
     n = 1 << log2n
@@ -512,6 +588,13 @@ def single_gpu(args, tm, eng, dev, curve, group):
         roof2 = roofline_of(args.curve, curve, group, n2, p2, acc2, args.extra_log2n)
         del bases2, scalars2
         torch.cuda.empty_cache()
+
+    # ---- the adjacent entry points ----
+    if not args.no_legs and not args.no_next_rows and (args.curve, group) == ("alt_bn128", 1):
+        try:
+            legs["next_rows"] = next_row_legs(args, eng, dev)
+        except Exception as e:   # reported extras: never lose the headline to them
+            legs["next_rows"] = {"failed": repr(e)}
 
     # ---- the other BASELINE configurations that fit one GPU (configs[2], configs[4]) ----
     if not args.no_legs and not args.no_other_configs and (args.curve, group) == ("alt_bn128", 1):

@@ -4,7 +4,7 @@
 for rep in 1 2; do
 for e in "$@"; do
   echo -n "[$rep] $e : "
-  env $e python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --extra-log2n 0 --no-other-configs --precomputed-c 0 2>/dev/null | python3 -c "
+  env $e python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --extra-log2n 0 --no-other-configs --no-next-rows --precomputed-c 0 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 p=d['config']['phases_ms']
