@@ -1042,7 +1042,13 @@ __global__ void __launch_bounds__(TPB, AMDMSM_ACC_WAVES) k_accumulate(const uint
             } while (bend == k);   // skip empty buckets (k < total = e[B-1] bounds the walk)
         }
         const uint32_t ent = staged[kk * TPB + threadIdx.x];
+#ifdef AMDMSM_EXP_BASE_MASK
+        // timing experiment only (wrong results): every base read lands in the first 2^MASK records, i.e. in the
+        // Infinity Cache -- the upper bound of what processing the input in cache-sized slices could save here
+        const uint32_t pi = ent & ((1u << AMDMSM_EXP_BASE_MASK) - 1u);
+#else
         const uint32_t pi = ent & 0x7fffffffu;
+#endif
         Aff<EA> p;
         load_aff(p, pi >= n_real ? endo_pts + (size_t)(pi - n_real) * AFFW : bases + (size_t)pi * AFFW);
         el_cneg(p.y, p.y, (ent >> 31) != 0);   // -(x, y) = (x, -y); (0,0) stays infinity

@@ -17,7 +17,8 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(HERE, "libamdmsm.so")
+# AMDMSM_LIBRARY: another build of the same ABI (A/B runs of experimental builds, tools/)
+SO_PATH = os.environ.get("AMDMSM_LIBRARY") or os.path.join(HERE, "libamdmsm.so")
 
 # curve / group ids (include/amdmsm.h)
 ALT_BN128, BLS12_377, BW6_761, BLS12_381 = 0, 1, 2, 3
@@ -437,14 +438,18 @@ class Engine:
                 self.free(p)
         return out
 
-    def batch_exp(self, curve, group, scalar_size, window, g, v, coeff=None, scalars_plain=False):
+    def batch_exp(self, curve, group, scalar_size, window, g, v, coeff=None, scalars_plain=False, out=None):
         """libff::batch_exp / batch_exp_with_coeff (multiexp.tcc:874-947) for the table that
-        get_window_table(scalar_size, window, g) would build: res[i] = (coeff *) v[i] * g."""
+        get_window_table(scalar_size, window, g) would build: res[i] = (coeff *) v[i] * g.
+        out: result array to fill (n, 3 * coordinate limbs) -- a caller that repeats the call passes the same
+        array again and spares the page faults of a fresh 100 MB allocation."""
         g = np.ascontiguousarray(g, dtype=np.uint64)
         v = np.ascontiguousarray(v, dtype=np.uint64)
         s = sizes(curve, group)
         n = v.shape[0]
-        out = np.zeros((n, s["g_bytes"] // 8), dtype=np.uint64)
+        if out is None:
+            out = np.zeros((n, s["g_bytes"] // 8), dtype=np.uint64)
+        assert out.dtype == np.uint64 and out.flags.c_contiguous and out.shape == (n, s["g_bytes"] // 8)
         cf = np.ascontiguousarray(coeff, dtype=np.uint64) if coeff is not None else None
         rc = self.lib.amdmsm_batch_exp(self.h, curve, group, ctypes.c_size_t(scalar_size), ctypes.c_size_t(window),
                                        _np_ptr(g), _np_ptr(v) if n else None, ctypes.c_size_t(n),
