@@ -1,3 +1,9 @@
+#!/usr/bin/env python3
+"""Steady-state slice of a rocprofv3 kernel trace of tools/pipelined_probe.py: every kernel (memsets included) between the
+fifth-last and the third-last k_accumulate with start / end / duration in us and its hardware queue.
+
+  python3 tools/show_trace.py <directory given to rocprofv3 -d>
+"""
 import csv,re,glob,sys
 f=sorted(glob.glob(sys.argv[1]+'/**/*kernel_trace.csv',recursive=True))[-1]
 rows=[]
