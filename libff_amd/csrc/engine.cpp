@@ -209,6 +209,11 @@ int num_windows(const group_vtable *vt, int c, bool glv) { return glv ? glv_wind
 // its n entries in a handful of buckets, which the second sort level (one workgroup per coarse
 // bin) processes almost serially -- such c are penalised rather than forbidden.
 //
+// (Round 3 re-sweep after the bucket reduction became plain sums, profiles/r03_sweep_c.txt: the choices below still hold --
+// 2^16..2^21 c = 16 with the split (c = 13: 1.04 vs 0.68 ms at 2^16), 2^23 c = 17, 2^24..2^26 c = 20; bls12_377 G1 2^22 c = 17,
+// bw6_761 G1 2^21 c = 16 (c = 14: 47.4 vs 45.2 ms), 2^24 c = 19; bls12_377 G2 2^21 c = 16 / 17, 2^24 c = 20.  A refit with
+// per-field entry and bucket prices chose worse for the wide fields and was dropped.  Left on the table: alt_bn128 G1 2^22 with
+// the split at c = 19 (7 windows) 7.16 vs 7.31-7.54 ms.)
 // Modelled time (ns, alt_bn128 G1 scale) of an MSM over n points with window size c, with or without
 // the endomorphism split.  The split doubles the digit columns and halves their length: about the
 // same number of bucket entries, half the buckets to reduce and half the final doublings
