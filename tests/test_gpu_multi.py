@@ -528,3 +528,48 @@ def test_opts_struct_size_is_checked(engine):
     rc = engine.lib.amdmsm_multi_exp(engine.h, 0, 1, None, ctypes.c_size_t(0), 0, None, ctypes.c_size_t(0),
                                      out.ctypes.data_as(ctypes.c_void_p), ctypes.byref(o))
     assert rc == 0
+
+
+def test_overlap_mode_parity():
+    """AMDMSM_OVERLAP=1 (experimental, off by default: DESIGN.md section 7): with several MSMs in flight the bulk of every MSM
+    runs on one engine stream in call order and its tail on a second one, the accumulation kernel one workgroup per CU
+    short.  Three contexts' worth of back-to-back MSMs with scalars that change every step, every result against the
+    oracle; also a group without overlap support (falls back to the plain path) and the one-at-a-time depth."""
+    import subprocess
+
+    code = r'''
+import os, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np, torch
+import libff_amd
+from libff_amd.distributed import ShardedMsm, numpy_words
+from oracle import port
+port.build()
+dev = torch.device("cuda", 0)
+eng = libff_amd.Engine(0)
+for curve, group, n in ((0, 1, 50001), (1, 1, 9001)):
+    sz = libff_amd.sizes(curve, group)
+    bases_h = port.bases_seq(curve, group, n, first=0)
+    bases = torch.empty((n, sz["affine_bytes"] // 8), dtype=torch.int64, device=dev)
+    eng.gen_bases_seq_device(curve, group, 0, n, bases.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    for depth in (3, 1, 2):
+        msm = ShardedMsm(eng, curve, group, depth=depth)
+        outs, wants, keep = [], [], []
+        for step in range(2 * depth + 1):
+            sc_h = port.scalars_sha512(curve, 300 * step + depth, n)
+            sc = torch.from_numpy(sc_h.view(np.int64)).to(dev)
+            keep.append(sc)
+            res, slot = msm.run(bases, sc, n, libff_amd.OUT_AFFINE)
+            outs.append((res, slot))
+            wants.append(port.multi_exp(curve, group, bases_h, sc_h, port.BDLO12_SIGNED, 1, chunks=8, omp=True))
+            if len(outs) >= depth:   # read a result before its slot is reused
+                r, sl = outs[-depth]
+                msm.streams[sl %% depth].synchronize()
+                assert (numpy_words(r) == wants[-depth]).all(), (curve, depth, step)
+        msm.synchronize()
+print("overlap-ok")
+''' % (REPO, os.path.join(REPO, "tests"))
+    env = dict(os.environ, AMDMSM_OVERLAP="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and "overlap-ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
