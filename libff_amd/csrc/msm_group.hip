@@ -694,9 +694,9 @@ __global__ void __launch_bounds__(NT) k_sort_fine(const uint32_t* __restrict__ t
                                                         const sort_key_t* __restrict__ tmp_key,
                                                         const uint32_t* __restrict__ coarse, size_t stride, int c, int hb,
                                                         uint32_t chunk_cap, uint32_t big_thresh, uint32_t big_cap,
-                                                        uint32_t* __restrict__ big, uint32_t* __restrict__ ends,
-                                                        uint32_t* __restrict__ lists) {
-    // dynamic LDS: 4 arrays of nfine words, chunk_cap payload words, chunk_cap fine keys (u16)
+                                                        uint32_t perchunk_words, uint32_t* __restrict__ big,
+                                                        uint32_t* __restrict__ ends, uint32_t* __restrict__ lists) {
+    // dynamic LDS: 4 arrays of nfine words, chunk_cap payload words, chunk_cap fine keys (u16), perchunk_words words
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     __shared__ uint32_t tmp[NT / 64 + 1];
     const uint32_t nbin = 1u << hb;
@@ -731,25 +731,49 @@ __global__ void __launch_bounds__(NT) k_sort_fine(const uint32_t* __restrict__ t
         return;
     }
     // pass A: sizes of the fine buckets of this bin -> ends[]
-    for (uint32_t j = threadIdx.x; j < nfine; j += NT) chist[j] = 0;
-    __syncthreads();
-    for (uint32_t k = threadIdx.x; k < m; k += NT) atomicAdd(&chist[key[k] & fmask], 1u);
+    // A bin of several chunks keeps one histogram per chunk (perchunk: room for them behind the staging area), so that
+    // pass B needs no second count of each chunk: two LDS atomics and two reads of the key per entry instead of three
+    // (the fine pass is bound by them: 6.2 ms of a 2^26-point MSM).
+    const uint32_t nch = (m + chunk_cap - 1) / chunk_cap;
+    const bool single = m <= chunk_cap;   // the bin is one chunk: pass A's histogram and scan are the chunk's
+    uint32_t* ch = reinterpret_cast<uint32_t*>(st_fine + chunk_cap);   // [nch][nfine]
+    const bool split_hist = !single && (size_t)nch * nfine <= perchunk_words;
+    if (split_hist) {
+        int sh = 0;
+        while ((1u << sh) < chunk_cap) ++sh;   // chunk_cap is a power of two
+        for (uint32_t j = threadIdx.x; j < nch * nfine; j += NT) ch[j] = 0;
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < m; k += NT) atomicAdd(&ch[(k >> sh) * nfine + (key[k] & fmask)], 1u);
+        __syncthreads();
+        for (uint32_t j = threadIdx.x; j < nfine; j += NT) {
+            uint32_t t = 0;
+            for (uint32_t q = 0; q < nch; ++q) t += ch[q * nfine + j];
+            chist[j] = t;
+        }
+    } else {
+        for (uint32_t j = threadIdx.x; j < nfine; j += NT) chist[j] = 0;
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < m; k += NT) atomicAdd(&chist[key[k] & fmask], 1u);
+    }
     __syncthreads();
     block_exclusive_scan<NT>(chist, fstart, nfine, tmp);
     for (uint32_t j = threadIdx.x; j < nfine; j += NT) e[j] = b0 + fstart[j] + chist[j];
     __syncthreads();
     // pass B: chunk-wise counting sort; fstart[f] advances as chunks are placed
-    const bool single = m <= chunk_cap;   // the bin is one chunk: pass A's histogram and scan are the chunk's
-    for (uint32_t c0 = 0; c0 < m; c0 += chunk_cap) {
+    uint32_t cidx = 0;
+    for (uint32_t c0 = 0; c0 < m; c0 += chunk_cap, ++cidx) {
         const uint32_t cm = (m - c0 < chunk_cap) ? m - c0 : chunk_cap;
+        const uint32_t* hist_c = split_hist ? ch + cidx * nfine : chist;   // this chunk's histogram
         if (single) {
             for (uint32_t j = threadIdx.x; j < nfine; j += NT) cstart[j] = ccur[j] = fstart[j];
         } else {
-            for (uint32_t j = threadIdx.x; j < nfine; j += NT) chist[j] = 0;
-            __syncthreads();
-            for (uint32_t k = threadIdx.x; k < cm; k += NT) atomicAdd(&chist[key[c0 + k] & fmask], 1u);
-            __syncthreads();
-            block_exclusive_scan<NT>(chist, cstart, nfine, tmp);
+            if (!split_hist) {
+                for (uint32_t j = threadIdx.x; j < nfine; j += NT) chist[j] = 0;
+                __syncthreads();
+                for (uint32_t k = threadIdx.x; k < cm; k += NT) atomicAdd(&chist[key[c0 + k] & fmask], 1u);
+                __syncthreads();
+            }
+            block_exclusive_scan<NT>(hist_c, cstart, nfine, tmp);
             for (uint32_t j = threadIdx.x; j < nfine; j += NT) ccur[j] = cstart[j];
         }
         __syncthreads();
@@ -765,7 +789,7 @@ __global__ void __launch_bounds__(NT) k_sort_fine(const uint32_t* __restrict__ t
             out[fstart[f] + (k - cstart[f])] = st_payload[k];
         }
         __syncthreads();
-        for (uint32_t j = threadIdx.x; j < nfine; j += NT) fstart[j] += chist[j];
+        for (uint32_t j = threadIdx.x; j < nfine; j += NT) fstart[j] += hist_c[j];
         __syncthreads();
     }
 }
@@ -2350,13 +2374,17 @@ void l_sort(hipStream_t st, const uint32_t* scalars, size_t n, int mont, int c, 
     hipLaunchKernelGGL(k_sort_coarse, dim3((unsigned)((ne + SORT_TILE - 1) / SORT_TILE), We), dim3(SORT_TPB), 0, st, digits,
                        ne, stride, c, hb, cursor, tmp_payload, tmp_key16);
     if (after_coarse) (void)hipEventRecord(after_coarse, st);
-    const size_t fine_lds = ((size_t)4 << sg.fb) * 4 + (size_t)sg.chunk_cap * 6;
+    // per-chunk histograms of a bin of up to 16 chunks, where they fit beside the staging area (<= 32 KiB)
+    static const bool split_hist = !(getenv("AMDMSM_SORT_SPLIT_HIST") && atoi(getenv("AMDMSM_SORT_SPLIT_HIST")) == 0);
+    uint32_t perchunk_words = 0;
+    if (split_hist && sg.chunk_cap >= 16384 && ((size_t)16 << sg.fb) * 4 <= 32768) perchunk_words = 16u << sg.fb;
+    const size_t fine_lds = ((size_t)4 << sg.fb) * 4 + (size_t)sg.chunk_cap * 6 + (size_t)perchunk_words * 4;
     if (sg.chunk_cap <= 4096)
         hipLaunchKernelGGL(k_sort_fine<256>, dim3(nbin, We), dim3(256), fine_lds, st, tmp_payload, tmp_key16, coarse, stride,
-                           c, hb, sg.chunk_cap, sg.big_thresh, sg.big_cap, big, ends, lists);
+                           c, hb, sg.chunk_cap, sg.big_thresh, sg.big_cap, perchunk_words, big, ends, lists);
     else
         hipLaunchKernelGGL(k_sort_fine<SORT_TPB>, dim3(nbin, We), dim3(SORT_TPB), fine_lds, st, tmp_payload, tmp_key16, coarse,
-                           stride, c, hb, sg.chunk_cap, sg.big_thresh, sg.big_cap, big, ends, lists);
+                           stride, c, hb, sg.chunk_cap, sg.big_thresh, sg.big_cap, perchunk_words, big, ends, lists);
     hipLaunchKernelGGL(k_sort_big_hist, dim3(2048), dim3(SORT_TPB), 0, st, tmp_key16, coarse, stride, c, hb, big, ends);
     hipLaunchKernelGGL(k_sort_big_scan, dim3(256), dim3(SORT_TPB), 0, st, coarse, c, hb, sg.big_cap, big, ends);
     const size_t big_lds = ((size_t)4 << sg.fb) * 4 + (size_t)SORT_TILE * 6;
