@@ -736,7 +736,7 @@ def multi_gpu(args, tm, eng, dev, rank, world, curve, group):
                         "all-gathers; value counts the scalar-muls of both; endomorphism split permitted (bases in the order-r subgroup)"}
             del jobs
             eng2.close()
-            eng.endomorphism = 0
+            eng.endomorphism = args.endomorphism
 
     out = {
         "metric": "G1 MSM throughput (scalar-muls/sec)" if group == 1 else "G2 MSM throughput (scalar-muls/sec)",

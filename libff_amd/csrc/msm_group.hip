@@ -1096,6 +1096,7 @@ __global__ void __launch_bounds__(TPB, AMDMSM_ACC_WAVES) k_accumulate(const uint
 }
 
 AMDMSM_DEV void wave_group_sum(Jac<E>& p, uint32_t G);
+AMDMSM_DEV void wave_group_sum_r(Jac<ER>& p, uint32_t G);
 
 // Closing the spanning buckets.  A span of up to INLINE_SPAN further lanes is summed by the
 // lane's own thread (the common case: buckets of about S entries); longer ones are queued and
@@ -1119,13 +1120,17 @@ AMDMSM_DEV uint32_t* fixup_queue_base(uint32_t* q, size_t lanes, int mid) {
     return q + 2 + (mid ? 2 * fixup_queue_cap_long(lanes) : 0);
 }
 
+// (The fix-up kernels hold their elements as the bucket reduction does -- ER: an Fq2 element over a pair of lanes for the
+// groups built with AMDMSM_ACC_SPLIT, RED_LANES physical lanes per logical lane -- so that they are not the one-wave-per-SIMD
+// kernels with spill space the packed form made them: bls12_377 G2 2^21 fix-up 1.16 -> see profiles/r03_experiments.txt.)
 __global__ void __launch_bounds__(64) k_accumulate_fixup(const uint32_t* __restrict__ ends,
                                                          const uint32_t* __restrict__ part_first,
                                                          const uint32_t* __restrict__ part_last,
                                                          const uint32_t* __restrict__ cont_bucket,
                                                          uint32_t* __restrict__ buckets, uint32_t* __restrict__ queue,
                                                          int W, uint32_t B, uint32_t S, uint32_t T) {
-    const size_t g = gtid();
+    const size_t g = gtid() / RED_LANES;
+    const bool first_of_pair = (threadIdx.x % RED_LANES) == 0;
     const size_t w = g / T;
     const uint32_t t = (uint32_t)(g % T);
     uint32_t b = NO_BUCKET, t_last = 0;
@@ -1138,7 +1143,7 @@ __global__ void __launch_bounds__(64) k_accumulate_fixup(const uint32_t* __restr
     const size_t lanes = (size_t)W * T;
 #pragma unroll
     for (int mid = 0; mid < 2; ++mid) {
-        const bool mine = mid ? (span > INLINE_SPAN && span <= MID_SPAN) : (span > MID_SPAN);
+        const bool mine = first_of_pair && (mid ? (span > INLINE_SPAN && span <= MID_SPAN) : (span > MID_SPAN));
         const unsigned long long m = __ballot(mine);
         if (m == 0) continue;
         const uint32_t lane = threadIdx.x & 63u;
@@ -1153,7 +1158,7 @@ __global__ void __launch_bounds__(64) k_accumulate_fixup(const uint32_t* __restr
         }
     }
     if (span == 0 || span > INLINE_SPAN) return;
-    Xyzz<E> acc, x;
+    Xyzz<ER> acc, x;
     load_xyzz(acc, part_last + g * ZZW);
 #ifndef AMDMSM_FIX_PRIO
 #define AMDMSM_FIX_PRIO 1
@@ -1194,16 +1199,16 @@ __global__ void __launch_bounds__(64) k_accumulate_compact(const uint32_t* __res
     if (ent_b >= total) return;
     // the bucket of the last entry before the block still runs in the block's last lane
     if (bucket_of_entry(e, B, (uint32_t)ent_a) != bucket_of_entry(e, B, (uint32_t)ent_b)) return;
-    const uint32_t lane = threadIdx.x & 63u;
-    Xyzz<E> acc, x;
+    const uint32_t lane = (threadIdx.x & 63u) / RED_LANES;   // reduction lane of the wave, RED_FOLD of them
+    Xyzz<ER> acc, x;
     xyzz_set_inf(acc);
-    for (uint32_t u = first + lane; u <= last; u += 64) {
+    for (uint32_t u = first + lane; u <= last; u += RED_FOLD) {
         load_xyzz(x, part_first + (w * T + u) * ZZW);
         xyzz_add(acc, acc, x);
     }
-    Jac<E> j;
+    Jac<ER> j;
     xyzz_to_jac(j, acc);
-    wave_group_sum(j, 64);
+    wave_group_sum_r(j, RED_FOLD);
     jac_to_xyzz(acc, j);
     if (lane == 0) store_xyzz(part_first + (w * T + first) * ZZW, acc);
 }
@@ -1221,17 +1226,19 @@ __global__ void __launch_bounds__(64, AMDMSM_TAIL_WAVES) k_accumulate_fixup_queu
     __builtin_amdgcn_s_setprio(3);
     const uint32_t count = queue[mid];
     const uint32_t* qb = queue + 2 + (mid ? 2 * fixup_queue_cap_long(lanes) : 0);
+    if (G > RED_FOLD) G = RED_FOLD;   // a wave holds RED_FOLD reduction lanes
     // every field product costs a wave about a microsecond whatever its lane count, so with
     // many queued buckets fewer lanes each (about one wave per SIMD in total) finish sooner
     if (mid) {
-        while (G > 1 && (size_t)count * G > 65536) G >>= 1;
+        while (G > 1 && (size_t)count * G * RED_LANES > 65536) G >>= 1;
     }
-    const uint32_t per_wave = 64u / G;
-    const uint32_t sub = (threadIdx.x & 63u) / G, lane = (threadIdx.x & 63u) % G;
+    const uint32_t per_wave = RED_FOLD / G;
+    const uint32_t rl = (threadIdx.x & 63u) / RED_LANES;   // reduction lane inside the wave
+    const uint32_t sub = rl / G, lane = rl % G;
     for (uint32_t q0 = blockIdx.x * per_wave; q0 < count; q0 += gridDim.x * per_wave) {
         const uint32_t q = q0 + sub;
         const bool live = q < count;
-        Xyzz<E> acc, x;
+        Xyzz<ER> acc, x;
         xyzz_set_inf(acc);
         size_t w = 0;
         uint32_t b = 0;
@@ -1254,9 +1261,9 @@ __global__ void __launch_bounds__(64, AMDMSM_TAIL_WAVES) k_accumulate_fixup_queu
                 xyzz_add(acc, acc, x);
             }
         }
-        Jac<E> j;
+        Jac<ER> j;
         xyzz_to_jac(j, acc);
-        wave_group_sum(j, G);
+        wave_group_sum_r(j, G);
         jac_to_xyzz(acc, j);
         if (live && lane == 0) store_xyzz(buckets + (w * B + b) * ZZW, acc);
     }
@@ -2457,10 +2464,10 @@ void l_accumulate_fixup(hipStream_t st, const uint32_t* ends, uint32_t* buckets,
     if (T / FIX_BLOCK >= 2)
         hipLaunchKernelGGL(k_accumulate_compact, dim3((unsigned)(W * (T / FIX_BLOCK - 1))), dim3(64), 0, st, ends,
                            part_first, W, B, S, T);
-    hipLaunchKernelGGL(k_accumulate_fixup, dim3(blocks_for((size_t)W * T, 64)), dim3(64), 0, st, ends, part_first,
+    hipLaunchKernelGGL(k_accumulate_fixup, dim3(blocks_for((size_t)W * T * RED_LANES, 64)), dim3(64), 0, st, ends, part_first,
                        part_last, cont_bucket, buckets, queue, W, B, S, T);
     const size_t lanes = (size_t)W * T;
-    const size_t cap_mid = fixup_queue_cap_mid(lanes) / (64 / MID_G) + 1, cap_long = fixup_queue_cap_long(lanes);
+    const size_t cap_mid = fixup_queue_cap_mid(lanes) / (RED_FOLD / MID_G) + 1, cap_long = fixup_queue_cap_long(lanes);
     hipLaunchKernelGGL(k_accumulate_fixup_queue, dim3((unsigned)(cap_mid < 8192 ? cap_mid : 8192)), dim3(64), 0, st, ends,
                        part_first, part_last, cont_bucket, buckets, queue, 1, MID_G, lanes, B, S, T);
     hipLaunchKernelGGL(k_accumulate_fixup_queue, dim3((unsigned)(cap_long < 2048 ? cap_long : 2048)), dim3(64), 0, st, ends,
