@@ -1228,10 +1228,10 @@ __global__ void __launch_bounds__(64, AMDMSM_TAIL_WAVES) k_accumulate_fixup_queu
     const uint32_t* qb = queue + 2 + (mid ? 2 * fixup_queue_cap_long(lanes) : 0);
     if (G > RED_FOLD) G = RED_FOLD;   // a wave holds RED_FOLD reduction lanes
     // every field product costs a wave about a microsecond whatever its lane count, so with
-    // many queued buckets fewer lanes each (about one wave per SIMD in total) finish sooner
-    if (mid) {
-        while (G > 1 && (size_t)count * G * RED_LANES > 65536) G >>= 1;
-    }
+    // many queued buckets fewer lanes each (about one wave per SIMD in total) finish sooner -- in both queues: the
+    // short top window of a large MSM queues thousands of buckets of ~64 lanes each (2^26 points, c = 20: 8192 of them;
+    // a wave per bucket took 0.85 ms, eight lanes per bucket take 0.2)
+    while (G > 1 && (size_t)count * G * RED_LANES > 65536) G >>= 1;
     const uint32_t per_wave = RED_FOLD / G;
     const uint32_t rl = (threadIdx.x & 63u) / RED_LANES;   // reduction lane inside the wave
     const uint32_t sub = rl / G, lane = rl % G;
