@@ -203,3 +203,35 @@ def test_headline_size_same_result_with_and_without(port):
     want = port.group_op(curve, group, 4, port.scalar_mul(curve, group, one, port.fr_from_bigint(curve, k_plain)[0]))
     assert (outs[0] == want).all()
 
+
+
+@pytest.mark.parametrize("cname", ["alt_bn128", "bls12_377", "bw6_761", "bls12_381"])
+def test_subgroup_vector_constants(cname):
+    """The device's subgroup test [a]P + [b]phi(P) == 0 (msm_group.hip lattice_subgroup_check) rests on three facts about
+    (a, b) = gen_params.subgroup_vector: a + b lambda = 0 (mod r) -- the test holds on the order-r subgroup --, its norm
+    a^2 - a b + b^2 is exactly r -- so (a + b phi^2)(a + b phi) = [r] and a passing point has [r]P = 0 --, and the
+    non-adjacent forms in the generated header recompose to a and b."""
+    gp_mod = _gen_params()
+    r = gp_mod.CURVES[cname]["r"]
+    gp = gp_mod.glv_params(cname)
+    a, b = gp["sub"]
+    lam = gp["lam"]
+    assert (a + b * lam) % r == 0 and a * a - a * b + b * b == r
+    assert max(abs(a).bit_length(), abs(b).bit_length()) <= (r.bit_length() + 1) // 2 + 1
+    for v in (a, b):
+        d = gp_mod.naf(abs(v))
+        assert sum(x << i for i, x in enumerate(d)) == abs(v)
+        assert all(not (d[i] and d[i + 1]) for i in range(len(d) - 1))
+    # the header the device code includes carries exactly these digits
+    hdr = open(os.path.join(ROOT, "libff_amd", "csrc", "curve_params.h")).read()
+    blk = hdr[hdr.index(f"struct {cname}_glv {{"):]
+    blk = blk[:blk.index("\n};")]
+
+    def words(name):
+        line = next(ln for ln in blk.splitlines() if f" {name}[" in ln)
+        return [int(x.rstrip("u"), 16) for x in line[line.index("{") + 1:line.index("}")].split(",")]
+
+    for nm, v in (("A", a), ("B", b)):
+        pos = sum(w << (32 * i) for i, w in enumerate(words(f"SUB_{nm}_POS")))
+        neg = sum(w << (32 * i) for i, w in enumerate(words(f"SUB_{nm}_NEG")))
+        assert pos - neg == v and pos & neg == 0
