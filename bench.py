@@ -82,6 +82,8 @@ def parse_args():
                          "what `value` and the roofline kernel timings are quoted on)")
     ap.add_argument("--also-pipelined", type=int, default=3,
                     help="N = 1: also measure the same workload with this many MSMs in flight; 0 disables")
+    ap.add_argument("--batch", type=int, default=4,
+                    help="N = 1: also time this many MSMs handed over as one batch (amdmsm_msm_device_batch); 0 / 1 disables")
     ap.add_argument("--precomputed-c", type=int, default=16,
                     help="N = 1: also time the precomputed-multiples MSM (multi_exp_stream_with_precompute's algorithm "
                          "on an HBM-resident table of [2^(jc)]P) with this window size; 0 disables")
@@ -507,6 +509,39 @@ def single_gpu(args, tm, eng, dev, curve, group):
                              "note": "consecutive MSMs on alternating streams / workspace slots: the few-wave tail of one "
                                      "overlaps the bulk kernels of the next; `value` stays the one-at-a-time figure"}
         msm = ShardedMsm(eng, curve, group, depth=1)
+
+    # ---- k MSMs handed over as ONE batch (amdmsm_msm_device_batch): the tails of all of them run as one set of kernels ----
+    if not args.no_legs and args.batch > 1:
+        kb = args.batch
+        outs = [torch.zeros(sz["g_bytes"] // 8, dtype=torch.int64, device=dev) for _ in range(kb)]
+        scs = [scalars] + [random_scalars(curve, n, dev, 2000 + j) for j in range(1, kb)]
+        bs = [bases] + [gen_inputs(eng, curve, group, 77 * j, n, dev, 1)[0] for j in range(1, kb)]
+        st_b = torch.cuda.Stream(dev)
+        torch.cuda.synchronize()
+
+        def batch_call():
+            eng.msm_device_batch(curve, group, [b.data_ptr() for b in bs], [x.data_ptr() for x in scs], n,
+                                 [o.data_ptr() for o in outs], out_form=libff_amd.OUT_LIBFF, window_bits=args.window_bits,
+                                 stream=st_b.cuda_stream)
+
+        for _ in range(2):
+            batch_call()
+        st_b.synchronize()
+        tm.fence()
+        reps = max(args.steps // kb, 3)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            batch_call()
+        phb = eng.get_timings()
+        st_b.synchronize()
+        tm.fence()
+        eb = time.perf_counter() - t0
+        legs["batched"] = {"msms_per_call": kb, "calls": reps, "value": n * kb * reps / eb, "unit": "scalar-muls/s",
+                           "ms_per_msm": eb / (kb * reps) * 1e3, "ms_per_call": eb / reps * 1e3, "phases_ms_last_call": phb,
+                           "note": f"{kb} MSMs of 2^{log2n} points (different bases and scalars) in one amdmsm_msm_device_batch call: "
+                                   "sort and accumulation MSM after MSM, fix-up / bucket reduction / Horner once over the windows "
+                                   "of all of them; `value` stays the one-at-a-time figure"}
+        del outs, scs, bs
 
     # ---- SURVEY §8(d) "end-to-end": scalars cross PCIe inside the timed region, bases resident
     #      (amdmsm_register_bases), result back on the host; and the plain host entry where the

@@ -146,6 +146,14 @@ int amdmsm_multi_exp_filter_one_zero(amdmsm_ctx *ctx, int curve, int group,
 int amdmsm_batch_to_special(amdmsm_ctx *ctx, int curve, int group, void *elems_xyz,
                             size_t stride_bytes, size_t n);
 
+/* k (<= 8) multi_exp calls of the same group, length and base form as ONE batch: what a prover that has several query
+ * vectors of its proving key and their scalar vectors ready (libsnark r1cs_gg_ppzksnark_prover: A, B, L, H) hands over
+ * instead of k calls of multiexp.tcc:643-688.  Same results as k amdmsm_multi_exp calls; the latency-bound tails of the
+ * k MSMs run as one set of kernels (amdmsm_msm_device_batch).  Registered base vectors are honoured per MSM. */
+int amdmsm_multi_exp_batch(amdmsm_ctx *ctx, int curve, int group, int k, const void *const *bases_xyz,
+                           size_t base_stride_bytes, int base_form, const void *const *scalars, size_t n,
+                           void *const *out_xyz, const amdmsm_opts *opts);
+
 /* Resident base vectors.  A prover calls multi_exp with the same base vector (its proving key,
  * libsnark r1cs_gg_ppzksnark_proving_key) proof after proof; the reference re-reads it from host
  * memory every time (multiexp.tcc:643-688 takes const iterators).  amdmsm_register_bases imports
@@ -257,6 +265,13 @@ int amdmsm_disk_decode_device(amdmsm_ctx *ctx, int curve, int group, const void 
                               int compressed, void *d_dst_affine, unsigned *status);
 int amdmsm_msm_device(amdmsm_ctx *ctx, int curve, int group, const void *d_bases_affine,
                       const void *d_scalars, size_t n, void *d_out_xyz, const amdmsm_opts *opts);
+/* k (<= 8) MSMs of the same group and length in one call: d_bases_affine[j] / d_scalars[j] / d_out_xyz[j] as for
+ * amdmsm_msm_device, all results in opts->out_form.  The reference has no such entry -- a prover calls multi_exp
+ * (multiexp.tcc:643-688) once per query vector of its proving key -- but those calls are independent, and on the device
+ * their latency-bound tails (bucket fix-up, reduction, final Horner) then run once over the windows of all k MSMs
+ * instead of once per MSM.  Same results as k single calls. */
+int amdmsm_msm_device_batch(amdmsm_ctx *ctx, int curve, int group, int k, const void *const *d_bases_affine,
+                            const void *const *d_scalars, size_t n, void *const *d_out_xyz, const amdmsm_opts *opts);
 /* The same with the table resident in HBM (288 GB hold [2^(jc)]P for 2^26 alt_bn128 G1 bases):
  * amdmsm_precompute_bases_device fills d_table[i * num_digits + j] = [2^(j*c)] P_i (compact
  * affine, n * num_digits records) from compact affine bases -- the device-side

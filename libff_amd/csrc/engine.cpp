@@ -179,6 +179,8 @@ struct plan_t {
     bool rowcol = false;
     uint32_t q_row = 0, q_col = 0;
     size_t off_rc = 0, off_planes = 0, off_winsum = 0, rc_points = 0;
+    int K = 1;                                  // MSMs the workspace holds side by side (amdmsm_msm_device_batch)
+    size_t big_stride = 0, endo_stride = 0;     // bytes per MSM of the big-bin sort scratch / the phi(P) records
     size_t list_stride = 0;
     bool glv = false;        // endomorphism split: the sorted columns are 2 * n_real half-length scalars
     size_t off_endo = 0;     // phi(P) = (beta x, y) of every base, compact affine
@@ -281,8 +283,10 @@ int choose_c(const group_vtable *vt, size_t n, bool glv = false, double *cost_ou
 // table_digits > 0: every scalar contributes table_digits entries (one per digit, pointing at
 // its precomputed multiple) to a single bucket set; n is then the number of ENTRIES.
 // glv: n counts the 2 x points digit columns of the endomorphism split
+// batch > 1: workspace for `batch` MSMs of the same shape side by side -- every per-window array holds batch * W windows, MSM j
+// owning windows [j * W, (j + 1) * W), so that the tail kernels run once over all of them (amdmsm_msm_device_batch)
 int make_plan(const group_vtable *vt, size_t n, int c_req, int L_req, plan_t &p, int S_req = 0, int table_digits = 0,
-              int G_req = 0, bool glv = false, bool overlap = false) {
+              int G_req = 0, bool glv = false, bool overlap = false, int batch = 1) {
     if (c_req < 0 || c_req > 24 || c_req == 1) return AMDMSM_ERR_BAD_ARG;
     if (table_digits && (c_req < 2 || c_req > 22)) return AMDMSM_ERR_BAD_ARG;
     if (glv && (table_digits || c_req > 22)) return AMDMSM_ERR_BAD_ARG;
@@ -308,7 +312,7 @@ int make_plan(const group_vtable *vt, size_t n, int c_req, int L_req, plan_t &p,
     // bls12_377 G2 2^22 L = 16 -> 32: 5.36 -> 4.42 ms; bw6_761 G1 under the endomorphism split
     // (12 x 2^15) L = 4 / 8 / 16: 8.1 / 5.6 / 6.8 ms.
     uint32_t L = 2u;
-    while (L < 64u && (size_t)p.W * p.B * red_lanes / L > (size_t)70000) L <<= 1;
+    while (L < 64u && (size_t)p.W * (size_t)batch * p.B * red_lanes / L > (size_t)70000) L <<= 1;
     if (L_req > 0) L = (uint32_t)L_req;
     while (L > p.B) L >>= 1;
     if (L == 0 || (L & (L - 1))) return AMDMSM_ERR_BAD_ARG;
@@ -336,28 +340,30 @@ int make_plan(const group_vtable *vt, size_t n, int c_req, int L_req, plan_t &p,
         p.T = (uint32_t)((n + S - 1) / S);
         if (p.T == 0) p.T = 1;
     }
+    p.K = batch;
+    const size_t Wt = (size_t)p.W * (size_t)batch;   // windows the workspace holds
     size_t off = 0;
     p.off_counts = off;
-    off = align_up(off + (size_t)p.W * p.B * 4, 256);
+    off = align_up(off + Wt * p.B * 4, 256);
     p.off_lists = off;
-    off = align_up(off + (size_t)p.W * p.list_stride * 4, 256);
+    off = align_up(off + Wt * p.list_stride * 4, 256);
     const size_t zz_bytes = (size_t)4 * vt->el_words * 4;   // (X, Y, ZZ, ZZZ) bucket accumulators
     p.off_buckets = off;
-    off = align_up(off + (size_t)p.W * p.B * zz_bytes, 256);
+    off = align_up(off + Wt * p.B * zz_bytes, 256);
     const size_t M = p.B / p.L;
     p.off_lvl0 = off;
-    off = align_up(off + (size_t)p.W * M * xyz_bytes, 256);
+    off = align_up(off + Wt * M * xyz_bytes, 256);
     p.off_lvl1 = off;
-    off = align_up(off + (size_t)p.W * (M / 2 + 1) * xyz_bytes, 256);   // first fold leaves at most M / 32 points
+    off = align_up(off + Wt * (M / 2 + 1) * xyz_bytes, 256);   // first fold leaves at most M / 32 points
     p.off_pfirst = off;
-    off = align_up(off + (size_t)p.W * p.T * zz_bytes, 256);
+    off = align_up(off + Wt * p.T * zz_bytes, 256);
     p.off_plast = off;
-    off = align_up(off + (size_t)p.W * p.T * zz_bytes, 256);
+    off = align_up(off + Wt * p.T * zz_bytes, 256);
     p.off_cont = off;
-    off = align_up(off + (size_t)p.W * p.T * 4, 256);
+    off = align_up(off + Wt * p.T * 4, 256);
     p.G = G_req > 0 ? std::min(std::min(G_req, MAX_GROUPS), p.W) : 1;
     p.off_queue = off;   // one fix-up queue per group, each sized for the largest group
-    p.queue_stride = align_up(fixup_queue_words((size_t)((p.W + p.G - 1) / p.G) * p.T) * 4, 256);
+    p.queue_stride = align_up(fixup_queue_words((size_t)((p.W + p.G - 1) / p.G) * (size_t)batch * p.T) * 4, 256);
     off = off + p.queue_stride * p.G;
     p.off_partial = off;
     off = align_up(off + (size_t)MAX_GROUPS * xyz_bytes, 256);
@@ -365,18 +371,19 @@ int make_plan(const group_vtable *vt, size_t n, int c_req, int L_req, plan_t &p,
     // (the coarse counters and the header of the big-bin scratch are cleared by ONE memset: the
     // scratch follows the counters directly)
     p.off_coarse = off;
-    off = align_up(off + (size_t)p.W * 1025 * 4, 256);
+    off = align_up(off + Wt * 1025 * 4, 256);
     p.off_big = off;
-    if (p.c <= 22) off = align_up(off + sort_geometry(n, p.c, p.W).big_words * 4, 256);
-    else off += 256;
+    p.big_stride = p.c <= 22 ? align_up(sort_geometry(n, p.c, p.W).big_words * 4, 256) : 256;   // per MSM of a batch
+    off += p.big_stride * (size_t)batch;
     p.off_cursor = off;
-    off = align_up(off + (size_t)p.W * 1024 * 4, 256);
+    off = align_up(off + Wt * 1024 * 4, 256);
     p.off_tmp_payload = off;
-    off = align_up(off + (size_t)p.W * p.list_stride * 4, 256);
+    off = align_up(off + Wt * p.list_stride * 4, 256);
     p.off_tmp_key = off;
-    off = align_up(off + (size_t)p.W * p.list_stride * 4, 256);   // 16-bit fine keys use half of it
+    off = align_up(off + Wt * p.list_stride * 4, 256);   // 16-bit fine keys use half of it
     p.off_endo = off;
-    if (glv) off = align_up(off + (n / 2) * (size_t)vt->el_words * 2 * 4, 256);
+    p.endo_stride = glv ? align_up((n / 2) * (size_t)vt->el_words * 2 * 4, 256) : 0;   // per MSM of a batch
+    off += p.endo_stride * (size_t)batch;
     // Bucket reduction as plain sums (row / column sums of the weight matrix, bit planes, one short
     // Horner per window) from c = 10 up; below that a window's few segments fold inside one wave of
     // k_reduce_segments.  AMDMSM_ROWCOL=0 keeps the segment kernels everywhere (A/B runs).
@@ -397,16 +404,16 @@ int make_plan(const group_vtable *vt, size_t n, int c_req, int L_req, plan_t &p,
         const bool one_wave = vt->fq_words >= 24 || vt->el_words > vt->fq_words;
         const size_t lane_budget = one_wave ? 70000 : 140000;
         uint32_t q = 4;
-        while (q < 64 && (size_t)p.W * p.B * red_lanes * 2 / q > lane_budget) q <<= 1;
+        while (q < 64 && Wt * p.B * red_lanes * 2 / q > lane_budget) q <<= 1;
         p.q_row = qr_env > 0 ? (uint32_t)qr_env : q;
         p.q_col = qc_env > 0 ? (uint32_t)qc_env : q;
         p.rc_points = R + 1 + C;
         p.off_rc = off;
-        off = align_up(off + (size_t)p.W * p.rc_points * xyz_bytes, 256);
+        off = align_up(off + Wt * p.rc_points * xyz_bytes, 256);
         p.off_planes = off;
-        off = align_up(off + (size_t)p.W * p.c * xyz_bytes, 256);
+        off = align_up(off + Wt * p.c * xyz_bytes, 256);
         p.off_winsum = off;
-        off = align_up(off + (size_t)p.W * xyz_bytes, 256);
+        off = align_up(off + Wt * xyz_bytes, 256);
     }
     p.total = off;
     return AMDMSM_OK;
@@ -672,6 +679,92 @@ int msm_device_impl(amdmsm_ctx *ctx, const group_vtable *vt, const uint32_t *d_b
     } else {
         record(ctx, sl, 5, st);
     }
+    if (ctx->timing) sl.last_ticket = (long long)ctx->ticket++;
+    sl.ev_valid = ctx->timing;
+    HIP_TRY(ctx, hipEventRecord(sl.done, st));
+    sl.used = true;
+    HIP_TRY(ctx, hipGetLastError());
+    return AMDMSM_OK;
+}
+
+// k MSMs of the same group and length in one call (amdmsm_msm_device_batch).  Sort and accumulation fill the device
+// and run MSM after MSM; the tail -- fix-up, bucket reduction, final Horner: dependent chains of a few waves, a quarter
+// of a 2^20-point MSM -- runs ONCE over the k * W windows of all of them, so its latency is paid once per batch
+// instead of once per MSM (2^20 points, k = 3: see profiles/r03_experiments.txt).  This is the overlap a prover's
+// back-to-back MSMs can really have on this device: in one stream, by making the latency-bound kernels wider.
+constexpr int MAX_BATCH = 8;
+int msm_device_batch_impl(amdmsm_ctx *ctx, const group_vtable *vt, int k, const uint32_t *const *d_bases,
+                          const uint32_t *const *d_scalars, size_t n, uint32_t *const *d_outs, const amdmsm_opts *opts) {
+    hipStream_t st = (opts && opts->stream) ? (hipStream_t)opts->stream : ctx->stream;
+    const int form = opts ? opts->out_form : AMDMSM_OUT_LIBFF;
+    const int mont = (opts && opts->scalars_plain) ? 0 : 1;
+    const bool glv = use_endomorphism(vt, n, opts, 0);
+    const size_t entries = glv ? 2 * n : n;
+    plan_t p;
+    int rc = make_plan(vt, entries, opts ? opts->window_bits : 0, opts ? opts->segment_len : 0, p, 0, 0, 0, glv, false, k);
+    if (rc) return fail(ctx, rc, "bad window_bits / segment_len");
+    if (p.c > 22) return fail(ctx, AMDMSM_ERR_BAD_ARG, "window_bits > 22 is not available for a batch");
+    const int slot_idx = (int)(ctx->next++ % (unsigned)ctx->depth);
+    ws_slot &sl = ctx->slots[slot_idx];
+    ctx->last_slot = slot_idx;
+    if (sl.used) HIP_TRY(ctx, hipStreamWaitEvent(st, sl.done, 0));
+    rc = ensure_ws(ctx, sl, p.total);
+    if (rc) return rc;
+    char *ws = (char *)sl.ws;
+    const size_t zzw = (size_t)vt->el_words * 4, xyzw = (size_t)vt->el_words * 3;
+    const size_t Wt = (size_t)p.W * (size_t)k;
+    uint32_t *counts = (uint32_t *)(ws + p.off_counts), *lists = (uint32_t *)(ws + p.off_lists);
+    uint32_t *buckets = (uint32_t *)(ws + p.off_buckets);
+    uint32_t *pfirst = (uint32_t *)(ws + p.off_pfirst), *plast = (uint32_t *)(ws + p.off_plast), *cont = (uint32_t *)(ws + p.off_cont);
+    record(ctx, sl, 0, st);
+    HIP_TRY(ctx, hipMemsetAsync(ws + p.off_coarse, 0, Wt * 1025 * 4, st));
+    for (int j = 0; j < k; ++j) HIP_TRY(ctx, hipMemsetAsync(ws + p.off_big + (size_t)j * p.big_stride, 0, 16, st));
+    HIP_TRY(ctx, hipMemsetAsync(buckets, 0, Wt * p.B * vt->el_words * 16, st));
+    HIP_TRY(ctx, hipMemsetAsync(ws + p.off_queue, 0, 8, st));
+    record(ctx, sl, 1, st);
+    for (int j = 0; j < k; ++j) {
+        const size_t w0 = (size_t)j * p.W;
+        uint32_t *lists_j = lists + w0 * p.list_stride, *counts_j = counts + w0 * p.B;
+        vt->sort(st, d_scalars[j], n, mont, p.c, p.W, (uint32_t *)(ws + p.off_coarse) + w0 * 1025,
+                 (uint32_t *)(ws + p.off_cursor) + w0 * 1024, (int32_t *)lists_j,
+                 (uint32_t *)(ws + p.off_tmp_payload) + w0 * p.list_stride, (uint32_t *)(ws + p.off_tmp_key) + w0 * p.list_stride,
+                 counts_j, lists_j, p.list_stride, (uint32_t *)(ws + p.off_big + (size_t)j * p.big_stride), glv ? 2 : 0, nullptr);
+        uint32_t *endo_j = glv ? (uint32_t *)(ws + p.off_endo + (size_t)j * p.endo_stride) : nullptr;
+        if (glv) vt->endo_points(st, d_bases[j], n, endo_j);
+        if (j == 0) record(ctx, sl, 2, st);
+        vt->accumulate(st, counts_j, lists_j, p.list_stride, d_bases[j], buckets + w0 * p.B * zzw, pfirst + w0 * p.T * zzw,
+                       plast + w0 * p.T * zzw, cont + w0 * p.T, p.W, p.B, p.S, p.T, endo_j, n, 0);
+    }
+    record(ctx, sl, 3, st);
+    vt->accumulate_fixup(st, counts, buckets, pfirst, plast, cont, (uint32_t *)(ws + p.off_queue), (int)Wt, p.B, p.S, p.T);
+    uint32_t *src;
+    if (p.rowcol) {
+        src = (uint32_t *)(ws + p.off_winsum);
+        vt->reduce_rowcol(st, buckets, (int)Wt, p.B, p.c, p.q_row, p.q_col, (uint32_t *)(ws + p.off_rc),
+                          (uint32_t *)(ws + p.off_planes), src);
+    } else {
+        const size_t M0 = p.B / p.L, cap1 = M0 / 2 + 1;
+        (void)cap1;
+        src = (uint32_t *)(ws + p.off_lvl0);
+        uint32_t *dst = (uint32_t *)(ws + p.off_lvl1);
+        vt->reduce_segments(st, buckets, (int)Wt, p.B, p.L, src);
+        const uint32_t fold = (uint32_t)vt->reduce_fold;
+        uint32_t M = (uint32_t)M0;
+        M /= std::min<uint32_t>(M, fold);
+        while (M > 1) {
+            if ((size_t)M * (64 / fold) <= 256) {
+                vt->sum_block(st, src, (int)Wt, M, dst);
+                M = 1;
+            } else {
+                vt->sum_butterfly(st, src, (int)Wt, M, dst);
+                M /= std::min<uint32_t>(M, fold);
+            }
+            std::swap(src, dst);
+        }
+    }
+    record(ctx, sl, 4, st);
+    vt->horner_batch(st, src, k, p.W, p.c, form, d_outs);
+    record(ctx, sl, 5, st);
     if (ctx->timing) sl.last_ticket = (long long)ctx->ticket++;
     sl.ev_valid = ctx->timing;
     HIP_TRY(ctx, hipEventRecord(sl.done, st));
@@ -996,6 +1089,27 @@ int amdmsm_msm_device(amdmsm_ctx *ctx, int curve, int group, const void *d_bases
     if (!d_out_xyz || (n && (!d_bases_affine || !d_scalars))) return fail(ctx, AMDMSM_ERR_BAD_ARG, "null pointer");
     return msm_device_ranges(ctx, vt, (const uint32_t *)d_bases_affine, (const uint32_t *)d_scalars, n,
                              (uint32_t *)d_out_xyz, opts);
+}
+
+int amdmsm_msm_device_batch(amdmsm_ctx *ctx, int curve, int group, int k, const void *const *d_bases_affine,
+                            const void *const *d_scalars, size_t n, void *const *d_out_xyz, const amdmsm_opts *opts) {
+    GET_VT(ctx, curve, group);
+    CHECK_OPTS(ctx, opts);
+    if (k < 1 || k > MAX_BATCH || !d_bases_affine || !d_scalars || !d_out_xyz) return fail(ctx, AMDMSM_ERR_BAD_ARG, "batch of 1 .. 8 MSMs");
+    for (int j = 0; j < k; ++j) {
+        if (!d_out_xyz[j] || (n && (!d_bases_affine[j] || !d_scalars[j]))) return fail(ctx, AMDMSM_ERR_BAD_ARG, "null pointer");
+    }
+    // one MSM, an empty one, or one too long for a single pass: the MSMs one after the other
+    if (k == 1 || n == 0 || n > max_range_points() || (size_t)k * n >= ((size_t)1 << 30)) {
+        for (int j = 0; j < k; ++j) {
+            const int rc = msm_device_ranges(ctx, vt, (const uint32_t *)d_bases_affine[j], (const uint32_t *)d_scalars[j], n,
+                                             (uint32_t *)d_out_xyz[j], opts);
+            if (rc) return rc;
+        }
+        return AMDMSM_OK;
+    }
+    return msm_device_batch_impl(ctx, vt, k, (const uint32_t *const *)d_bases_affine, (const uint32_t *const *)d_scalars, n,
+                                 (uint32_t *const *)d_out_xyz, opts);
 }
 
 size_t amdmsm_precompute_num_digits(int curve, size_t c) {
@@ -1512,6 +1626,72 @@ int amdmsm_multi_exp_filter_one_zero(amdmsm_ctx *ctx, int curve, int group, cons
     GET_VT(ctx, curve, group);
     CHECK_OPTS(ctx, opts);
     return host_multi_exp(ctx, vt, bases_xyz, base_stride_bytes, base_form, scalars, n, out_xyz, opts, stats);
+}
+
+// k multi_exp calls of one group and length as ONE batch (amdmsm_msm_device_batch over host vectors): scalars over PCIe
+// per MSM, bases from the resident copies where registered (amdmsm_register_bases) and uploaded + imported otherwise.
+int amdmsm_multi_exp_batch(amdmsm_ctx *ctx, int curve, int group, int k, const void *const *bases_xyz,
+                           size_t base_stride_bytes, int base_form, const void *const *scalars, size_t n,
+                           void *const *out_xyz, const amdmsm_opts *opts) {
+    GET_VT(ctx, curve, group);
+    CHECK_OPTS(ctx, opts);
+    if (k < 1 || k > MAX_BATCH || !bases_xyz || !scalars || !out_xyz) return fail(ctx, AMDMSM_ERR_BAD_ARG, "batch of 1 .. 8 MSMs");
+    size_t stride = base_stride_bytes;
+    for (int j = 0; j < k; ++j) {
+        const int rcj = check_host_args(ctx, vt, bases_xyz[j], stride, scalars[j], n, out_xyz[j]);
+        if (rcj) return rcj;
+    }
+    if (k == 1 || n == 0 || n > max_range_points() || (size_t)k * n >= ((size_t)1 << 30)) {
+        for (int j = 0; j < k; ++j) {
+            const int rcj = host_multi_exp(ctx, vt, bases_xyz[j], stride, base_form, scalars[j], n, out_xyz[j], opts, nullptr);
+            if (rcj) return rcj;
+        }
+        return AMDMSM_OK;
+    }
+    const size_t xyz_bytes = (size_t)vt->el_words * 12, aff_bytes = (size_t)vt->el_words * 8, fr_bytes = (size_t)vt->fr_words * 4;
+    hipStream_t st = ctx->stream;
+    int rc = ensure_buf(ctx, ctx->hb_out, (size_t)k * xyz_bytes);
+    if (rc == AMDMSM_OK) rc = ensure_buf(ctx, ctx->hb_sc, (size_t)k * n * fr_bytes);
+    if (rc) return rc;
+    const uint32_t *d_b[MAX_BATCH], *d_s[MAX_BATCH];
+    uint32_t *d_o[MAX_BATCH];
+    int missing = 0;
+    for (int j = 0; j < k; ++j) {
+        d_b[j] = (const uint32_t *)find_resident_bases(ctx, vt, bases_xyz[j], stride, base_form, n);
+        if (!d_b[j] && auto_cache_bases(ctx, vt, bases_xyz[j], stride, base_form, n))
+            d_b[j] = (const uint32_t *)find_resident_bases(ctx, vt, bases_xyz[j], stride, base_form, n);
+        if (!d_b[j]) ++missing;
+    }
+    if (missing) {
+        rc = ensure_buf(ctx, ctx->hb_src, n * stride);
+        if (rc == AMDMSM_OK) rc = ensure_buf(ctx, ctx->hb_aff, (size_t)missing * n * aff_bytes);
+        if (rc) return rc;
+    }
+    int slot = 0;
+    for (int j = 0; j < k; ++j) {
+        d_s[j] = (const uint32_t *)((char *)ctx->hb_sc.p + (size_t)j * n * fr_bytes);
+        d_o[j] = (uint32_t *)((char *)ctx->hb_out.p + (size_t)j * xyz_bytes);
+        HIP_TRY(ctx, hipMemcpyAsync((void *)d_s[j], scalars[j], n * fr_bytes, hipMemcpyHostToDevice, st));
+        if (!d_b[j]) {
+            uint32_t *aff = (uint32_t *)((char *)ctx->hb_aff.p + (size_t)slot++ * n * aff_bytes);
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->hb_src.p, bases_xyz[j], n * stride, hipMemcpyHostToDevice, st));
+            vt->import_bases(st, (const uint32_t *)ctx->hb_src.p, stride / 4, base_form == AMDMSM_FORM_SPECIAL, n, aff);
+            HIP_TRY(ctx, hipGetLastError());
+            d_b[j] = aff;
+        }
+    }
+    amdmsm_opts o = AMDMSM_OPTS_INIT;
+    if (opts) o = *opts;
+    else o.out_form = AMDMSM_OUT_LIBFF;
+    o.stream = st;
+    rc = msm_device_batch_impl(ctx, vt, k, d_b, d_s, n, d_o, &o);
+    if (rc) {
+        (void)hipDeviceSynchronize();
+        return rc;
+    }
+    for (int j = 0; j < k; ++j) HIP_TRY(ctx, hipMemcpyAsync(out_xyz[j], d_o[j], xyz_bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    return AMDMSM_OK;
 }
 
 int amdmsm_register_bases(amdmsm_ctx *ctx, int curve, int group, const void *bases_xyz, size_t base_stride_bytes,

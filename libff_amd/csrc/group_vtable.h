@@ -144,6 +144,9 @@ struct group_vtable {
     // Jacobian, may be null) = value carried in from the windows above window_sums[W-1]
     void (*horner)(hipStream_t, const uint32_t* window_sums, int W, int c, int form, const uint32_t* init,
                    uint32_t* out);
+    // the same for k MSMs at once: MSM j's W window sums start at window_sums[j * W], its result goes to outs[j]
+    // (k <= 8; one wave per MSM, all chains side by side)
+    void (*horner_batch)(hipStream_t, const uint32_t* window_sums, int k, int W, int c, int form, uint32_t* const* outs);
     // sum of k engine-Jacobian points
     void (*sum_points)(hipStream_t, const uint32_t* pts, int k, int form, uint32_t* out);
     // synthetic bases: dst[i] = (first + i + 1) * G::one(), compact affine

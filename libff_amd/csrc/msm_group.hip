@@ -1701,6 +1701,21 @@ __global__ void __launch_bounds__(64 * WH_MAX_GROUPS) k_window_horner(const uint
     if (threadIdx.x == 0) store_jac(out + (size_t)blockIdx.x * XYZW, res);
 }
 
+// k Horner chains at once (amdmsm_msm_device_batch): block j folds the W window sums of MSM j
+struct horner_outs {
+    uint32_t* p[8];
+};
+__global__ void __launch_bounds__(64) k_horner_batch(const uint32_t* __restrict__ window_sums, int W, int c, int form,
+                                                     horner_outs outs) {
+    __builtin_amdgcn_s_setprio(3);
+    Jac<E> res;
+    horner_chain(res, window_sums + (size_t)blockIdx.x * W * XYZW, W, c, nullptr);
+    uint32_t* out = outs.p[0];
+#pragma unroll
+    for (int j = 1; j < 8; ++j) out = (blockIdx.x == (unsigned)j) ? outs.p[j] : out;
+    if (threadIdx.x == 0) store_out(out, res, form);
+}
+
 // plain sum of k engine-Jacobian points by one wave: the Horner chain with no doublings, i.e. on
 // lane-split coordinates (partials of chunked / multi-GPU calls, multiexp.tcc:681-687)
 __global__ void __launch_bounds__(64) k_sum_points(const uint32_t* __restrict__ pts, int k, int form,
@@ -2520,6 +2535,11 @@ void l_reduce_rowcol(hipStream_t st, const uint32_t* buckets, int W, uint32_t B,
 void l_horner(hipStream_t st, const uint32_t* window_sums, int W, int c, int form, const uint32_t* init, uint32_t* out) {
     hipLaunchKernelGGL(k_horner, dim3(1), dim3(64), 0, st, window_sums, W, c, form, init, out);
 }
+void l_horner_batch(hipStream_t st, const uint32_t* window_sums, int k, int W, int c, int form, uint32_t* const* outs) {
+    horner_outs o = {};
+    for (int j = 0; j < k && j < 8; ++j) o.p[j] = outs[j];
+    hipLaunchKernelGGL(k_horner_batch, dim3((unsigned)k), dim3(64), 0, st, window_sums, W, c, form, o);
+}
 void l_sum_points(hipStream_t st, const uint32_t* pts, int k, int form, uint32_t* out) {
     hipLaunchKernelGGL(k_sum_points, dim3(1), dim3(64), 0, st, pts, k, form, out);
 }
@@ -2615,7 +2635,7 @@ void l_madd_bench(hipStream_t st, const uint32_t* pts, uint32_t* out, size_t nth
 const group_vtable g_vt = {
     GP::CURVE, GP::GROUP, FRW, EW, FQ::N, FR::BITS, GP::LIBFF_PROJECTIVE ? 1 : 0, (int)RED_FOLD, FR::R,
     GLV::BOUND_LOG2_X1000, GP::SUBGROUP_CHECK == 0 ? 1 : 0, GLV::LAMBDA, l_endo_points, l_glv_digits,
-    l_import_bases, l_precompute_table, l_count, l_scatter, l_scalar_stats, l_sort, l_accumulate, l_accumulate_resident_lanes, (AMDMSM_OVERLAP_OK && ACC_OVERLAP_LDS) ? 1 : 0, l_accumulate_fixup, l_reduce_segments, l_sum_butterfly, l_sum_block, l_reduce_rowcol, l_horner, l_sum_points,
+    l_import_bases, l_precompute_table, l_count, l_scatter, l_scalar_stats, l_sort, l_accumulate, l_accumulate_resident_lanes, (AMDMSM_OVERLAP_OK && ACC_OVERLAP_LDS) ? 1 : 0, l_accumulate_fixup, l_reduce_segments, l_sum_butterfly, l_sum_block, l_reduce_rowcol, l_horner, l_horner_batch, l_sum_points,
     l_gen_bases_seq, l_export_affine, l_ffi_decode_points, l_ffi_decode_scalars, l_ffi_encode_point, l_disk_decode, l_disk_decode_compressed, l_fixed_base_exp, l_field_op, l_group_op, l_digits, l_mul_bench, l_madd_bench,
 };
 

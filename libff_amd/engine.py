@@ -44,7 +44,7 @@ EXPORTED_SYMBOLS = [
     "amdmsm_abi_version", "amdmsm_device_count", "amdmsm_ctx_create", "amdmsm_ctx_destroy", "amdmsm_strerror",
     "amdmsm_last_error", "amdmsm_sizes", "amdmsm_plan", "amdmsm_plan_ex", "amdmsm_endomorphism_info",
     "amdmsm_endomorphism_digits_device", "amdmsm_pippenger_optimal_c",
-    "amdmsm_bdlo12_signed_optimal_c", "amdmsm_multi_exp", "amdmsm_multi_exp_filter_one_zero",
+    "amdmsm_bdlo12_signed_optimal_c", "amdmsm_multi_exp", "amdmsm_multi_exp_batch", "amdmsm_multi_exp_filter_one_zero",
     "amdmsm_multi_exp_multi", "amdmsm_multi_exp_filter_one_zero_multi", "amdmsm_msm_device_multi", "amdmsm_register_bases", "amdmsm_unregister_bases",
     "amdmsm_invalidate_bases",
     "amdmsm_batch_to_special", "amdmsm_batch_exp", "amdmsm_get_batch_exp_timings", "amdmsm_multi_exp_stream", "amdmsm_multi_exp_stream_file",
@@ -52,7 +52,7 @@ EXPORTED_SYMBOLS = [
     "amdmsm_precompute_num_digits", "amdmsm_multi_exp_stream_with_precompute",
     "amdmsm_multi_exp_stream_with_precompute_file", "amdmsm_precompute_bases_device",
     "amdmsm_msm_precomputed_device", "amdmsm_import_bases_device", "amdmsm_export_affine_device",
-    "amdmsm_msm_device", "amdmsm_sum_points_device", "amdmsm_gen_bases_seq_device",
+    "amdmsm_msm_device", "amdmsm_msm_device_batch", "amdmsm_sum_points_device", "amdmsm_gen_bases_seq_device",
     "amdmsm_set_timing", "amdmsm_get_timings", "amdmsm_last_timing_ticket", "amdmsm_get_timings_by_ticket",
     "amdmsm_set_pipeline_depth", "amdmsm_last_slot",
     "amdmsm_get_slot_timings", "amdmsm_field_op_device", "amdmsm_group_op_device",
@@ -297,6 +297,25 @@ class Engine:
             self._check(rc, "amdmsm_multi_exp")
         return self.sum_points(curve, group, partials, out_form=out_form)
 
+    def multi_exp_batch(self, curve, group, bases_list, scalars_list, base_form=multi_exp_base_form_normal,
+                        out_form=OUT_AFFINE, window_bits=0, scalars_plain=False):
+        """amdmsm_multi_exp_batch: len(bases_list) multi_exp calls of one group and length as one batch; list of results."""
+        k = len(bases_list)
+        bs = [np.ascontiguousarray(b, dtype=np.uint64) for b in bases_list]
+        ss = [np.ascontiguousarray(x, dtype=np.uint64) for x in scalars_list]
+        s = sizes(curve, group)
+        n = bs[0].shape[0]
+        assert all(b.shape == bs[0].shape for b in bs) and all(x.shape[0] == n for x in ss)
+        outs = [np.zeros(s["g_bytes"] // 8, dtype=np.uint64) for _ in range(k)]
+        pb = (ctypes.c_void_p * k)(*[_np_ptr(b) for b in bs])
+        ps = (ctypes.c_void_p * k)(*[_np_ptr(x) for x in ss])
+        po = (ctypes.c_void_p * k)(*[_np_ptr(o) for o in outs])
+        o = self._opts(window_bits=window_bits, out_form=out_form, scalars_plain=scalars_plain)
+        rc = self.lib.amdmsm_multi_exp_batch(self.h, curve, group, k, pb, ctypes.c_size_t(s["g_bytes"]), base_form, ps,
+                                             ctypes.c_size_t(n), po, ctypes.byref(o))
+        self._check(rc, "amdmsm_multi_exp_batch")
+        return outs
+
     def register_bases(self, curve, group, bases, base_form=multi_exp_base_form_normal):
         """amdmsm_register_bases: keep ``bases`` (the very numpy buffer -- the registry is keyed on its
         address) resident in HBM; later host-buffer calls on it or on row ranges of it skip the base
@@ -519,6 +538,18 @@ class Engine:
         self._check(self.lib.amdmsm_msm_device(self.h, curve, group, _vp(d_bases_affine),
                                                _vp(d_scalars), ctypes.c_size_t(n),
                                                _vp(d_out_xyz), ctypes.byref(o)), "amdmsm_msm_device")
+
+    def msm_device_batch(self, curve, group, d_bases_affine, d_scalars, n, d_out_xyz, out_form=OUT_LIBFF,
+                         window_bits=0, scalars_plain=False, stream=None):
+        """amdmsm_msm_device_batch: len(d_bases_affine) MSMs of n points each (lists of device pointers) in one call;
+        the tails of all of them run as one set of kernels."""
+        k = len(d_bases_affine)
+        pb = (ctypes.c_void_p * k)(*[_vp(x) for x in d_bases_affine])
+        ps = (ctypes.c_void_p * k)(*[_vp(x) for x in d_scalars])
+        po = (ctypes.c_void_p * k)(*[_vp(x) for x in d_out_xyz])
+        o = self._opts(window_bits, 0, out_form, scalars_plain, stream)
+        self._check(self.lib.amdmsm_msm_device_batch(self.h, curve, group, k, pb, ps, ctypes.c_size_t(n), po, ctypes.byref(o)),
+                    "amdmsm_msm_device_batch")
 
     def precompute_bases_device(self, curve, group, d_bases_affine, n, c, num_digits, d_table, stream=None):
         self._check(self.lib.amdmsm_precompute_bases_device(

@@ -180,6 +180,36 @@ static void check_headline_size()
     }
 }
 
+// libff_amd::multi_exp_batch: three (bases, scalars) pairs as one batch == the three single multi_exp calls
+template<typename G, typename Fr> void check_batch(const char *name, size_t n)
+{
+    std::vector<std::vector<G>> bases(3);
+    std::vector<std::vector<Fr>> scalars(3);
+    for (size_t j = 0; j < 3; ++j) {
+        G cur = Fr(7 + 5 * j) * G::one();
+        for (size_t i = 0; i < n; ++i) {
+            bases[j].push_back(cur);
+            cur = cur + G::one();
+            scalars[j].push_back(SHA512_rng<Fr>(5000 * (j + 1) + i));
+        }
+        batch_to_special<G>(bases[j]);
+    }
+    scalars[1][0] = Fr::zero();
+    scalars[2][n / 2] = Fr::one();
+    const std::vector<G> got = libff_amd::multi_exp_batch<G, Fr, multi_exp_base_form_special>(
+        {&bases[0], &bases[1], &bases[2]}, {&scalars[0], &scalars[1], &scalars[2]});
+    bool ok = got.size() == 3;
+    for (size_t j = 0; ok && j < 3; ++j) {
+        const G expect = multi_exp<G, Fr, multi_exp_method_naive_plain>(
+            bases[j].cbegin(), bases[j].cend(), scalars[j].cbegin(), scalars[j].cend(), 1);
+        ok = got[j] == expect;
+    }
+    printf("%-14s batch of 3 x %zu: %s\n", name, n, ok ? "ok" : "MISMATCH");
+    if (!ok) {
+        ++failures;
+    }
+}
+
 int main()
 {
     // SHIM_CHECK_MIN_SPLIT=<points>: with AMDMSM_DEVICES="0,0" (two contexts on one GPU) even the
@@ -207,6 +237,8 @@ int main()
     check_group<bw6_761_G2, bw6_761_Fr>("bw6_761_G2", {1, 5, 300});
     check_group<bls12_381_G1, bls12_381_Fr>("bls12_381_G1", {1, 5, 1000});
     check_group<bls12_381_G2, bls12_381_Fr>("bls12_381_G2", {1, 5, 300});
+    check_batch<alt_bn128_G1, alt_bn128_Fr>("alt_bn128_G1", 3000);
+    check_batch<bls12_377_G2, bls12_377_Fr>("bls12_377_G2", 400);
     if (!std::getenv("SHIM_CHECK_SKIP_LARGE")) {
         check_headline_size();
     }

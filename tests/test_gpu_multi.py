@@ -573,3 +573,69 @@ print("overlap-ok")
     env = dict(os.environ, AMDMSM_OVERLAP="1")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0 and "overlap-ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+@pytest.mark.parametrize("name,curve,group,n,k", [("alt_bn128_g1", 0, 1, 30001, 3), ("bls12_377_g2", 1, 2, 5003, 2),
+                                                   ("bw6_761_g1", 2, 1, 2500, 4), ("alt_bn128_g1", 0, 1, 700, 8)])
+def test_msm_device_batch(engine, port, name, curve, group, n, k):
+    """amdmsm_msm_device_batch: k MSMs of one group and length in one call -- different bases (R32 sets shifted against each
+    other, (i+1)G, repeated points) and different scalars per MSM (one with 0 / 1 / r - 1 and a heavy hitter) -- every result
+    against the oracle's multi_exp of that pair; once more with a forced window size; and k = 1."""
+    s = libff_amd.sizes(curve, group)
+    aw = s["affine_bytes"] // 8
+    sets, wants = [], []
+    for j in range(k):
+        if j % 3 == 0:
+            b = port.bases_seq(curve, group, n, first=1000 * j)
+        elif j % 3 == 1:
+            b = np.roll(port.bases_r32(curve, group, n), 5 * j, axis=0)
+        else:
+            b = np.repeat(port.bases_seq(curve, group, (n + 6) // 7, first=3), 7, axis=0)[:n]
+        sc = port.scalars_sha512(curve, 40 * j + 1, n)
+        if j == 1:
+            sc[0:n:9] = 0
+            sc[1:n:13] = small_scalars_mont(port, curve, [1])[0]
+            sc[2:n:5] = sc[2]
+        sets.append((np.ascontiguousarray(b[:, :aw]), sc))
+        wants.append(port.multi_exp(curve, group, b, sc, port.BDLO12_SIGNED, port.FORM_SPECIAL, chunks=8, omp=True))
+    ptrs = []
+    try:
+        for b, sc in sets:
+            d_b, d_s, d_o = engine.malloc(b.nbytes), engine.malloc(sc.nbytes), engine.malloc(s["g_bytes"])
+            engine.h2d(d_b, b)
+            engine.h2d(d_s, sc)
+            ptrs.append((d_b, d_s, d_o))
+        for wb, kk in ((0, k), (12, k), (0, 1)):
+            for _, _, d_o in ptrs:
+                engine.h2d(d_o, np.zeros(s["g_bytes"] // 8, dtype=np.uint64))
+            engine.msm_device_batch(curve, group, [p[0].value for p in ptrs[:kk]], [p[1].value for p in ptrs[:kk]], n,
+                                    [p[2].value for p in ptrs[:kk]], out_form=libff_amd.OUT_AFFINE, window_bits=wb)
+            engine.synchronize()
+            for j in range(kk):
+                out = np.zeros(s["g_bytes"] // 8, dtype=np.uint64)
+                engine.d2h(out, ptrs[j][2])
+                assert (out == wants[j]).all(), (wb, kk, j)
+    finally:
+        for t in ptrs:
+            for q in t:
+                engine.free(q)
+
+
+def test_multi_exp_batch_host_entry(engine, port):
+    """amdmsm_multi_exp_batch (host vectors; what libff_amd::multi_exp_batch of the C++ shim calls): three pairs, one of the
+    base vectors registered (resident) and two uploaded, normal-form bases; each result against the oracle; then k = 1."""
+    curve, group, n = 0, 1, 20011
+    bases = [port.bases_seq(curve, group, n, first=11 * j) for j in range(3)]
+    # genuinely projective records for one of them: 2P_i, not normalised
+    bases[1] = port.group_op(curve, group, 2, bases[1]) if hasattr(port, "group_op_n") else bases[1]
+    scs = [port.scalars_sha512(curve, 900 + j, n) for j in range(3)]
+    wants = [port.multi_exp(curve, group, b, s_, port.BDLO12_SIGNED, port.FORM_NORMAL, chunks=8, omp=True) for b, s_ in zip(bases, scs)]
+    h = engine.register_bases(curve, group, bases[2], libff_amd.multi_exp_base_form_normal)
+    try:
+        got = engine.multi_exp_batch(curve, group, bases, scs, base_form=libff_amd.multi_exp_base_form_normal)
+        for j in range(3):
+            assert (got[j] == wants[j]).all(), j
+        got = engine.multi_exp_batch(curve, group, bases[:1], scs[:1], base_form=libff_amd.multi_exp_base_form_normal)
+        assert (got[0] == wants[0]).all()
+    finally:
+        engine.unregister_bases(h)
