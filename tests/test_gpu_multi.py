@@ -623,11 +623,9 @@ def test_msm_device_batch(engine, port, name, curve, group, n, k):
 
 def test_multi_exp_batch_host_entry(engine, port):
     """amdmsm_multi_exp_batch (host vectors; what libff_amd::multi_exp_batch of the C++ shim calls): three pairs, one of the
-    base vectors registered (resident) and two uploaded, normal-form bases; each result against the oracle; then k = 1."""
+    base vectors registered (resident) and two uploaded; each result against the oracle; then k = 1."""
     curve, group, n = 0, 1, 20011
     bases = [port.bases_seq(curve, group, n, first=11 * j) for j in range(3)]
-    # genuinely projective records for one of them: 2P_i, not normalised
-    bases[1] = port.group_op(curve, group, 2, bases[1]) if hasattr(port, "group_op_n") else bases[1]
     scs = [port.scalars_sha512(curve, 900 + j, n) for j in range(3)]
     wants = [port.multi_exp(curve, group, b, s_, port.BDLO12_SIGNED, port.FORM_NORMAL, chunks=8, omp=True) for b, s_ in zip(bases, scs)]
     h = engine.register_bases(curve, group, bases[2], libff_amd.multi_exp_base_form_normal)
