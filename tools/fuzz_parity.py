@@ -24,7 +24,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=120)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--max-n", type=int, default=4000)
-    ap.add_argument("--mode", choices=("multi_exp", "precomputed"), default="multi_exp")
+    ap.add_argument("--mode", choices=("multi_exp", "precomputed", "batch"), default="multi_exp")
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
     eng = libff_amd.Engine(0)
@@ -61,6 +61,47 @@ def main():
             print(f"MISMATCH it={it} {name} n={n} c={c} D={D}", flush=True)
         if it % 25 == 0:
             print(f"[fuzz precomputed] {it} cases, {fails} mismatches", flush=True)
+    while args.mode == "batch" and time.time() < t_end:
+        # amdmsm_multi_exp_batch: k pairs of one group and length, every result against the oracle's single multi_exp
+        name, curve, group = GROUPS[rng.integers(len(GROUPS))]
+        heavy = group == 2 or curve == 2
+        n = int(rng.integers(1, (args.max_n // 4 if heavy else args.max_n) + 1))
+        k = int(rng.integers(1, 9))
+        form = int(rng.integers(2))
+        bl, sl = [], []
+        for j in range(k):
+            sc = port.scalars_sha512(curve, int(rng.integers(1 << 30)), n)
+            r = rng.random()
+            if r < 0.2:
+                sc[rng.random(n) < 0.7] = sc[0]
+            elif r < 0.4:
+                sm = small_scalars_mont(port, curve, [0, 1, 2])
+                pick = rng.integers(0, 6, size=n)
+                for v in range(3):
+                    sc[pick == v] = sm[v]
+            b = port.bases_seq(curve, group, n, first=int(rng.integers(0, 1 << 20))) if rng.random() < 0.6 else \
+                np.roll(port.bases_r32(curve, group, n), int(rng.integers(32)), axis=0)
+            if n >= 3 and rng.random() < 0.2:
+                b[2] = port.group_consts(curve, group)[1]
+            bl.append(b)
+            sl.append(sc)
+        c = int(rng.choice([0, 0, 0, 3, 7, 10, 11, 13, 16]))
+        eng.endomorphism = int(rng.choice([0, 1, 2, -1]))
+        if rng.random() < 0.3 and n >= 1:
+            h = eng.register_bases(curve, group, bl[0], form)
+        else:
+            h = None
+        got = eng.multi_exp_batch(curve, group, bl, sl, base_form=form, window_bits=c)
+        if h is not None:
+            eng.unregister_bases(h)
+        it += 1
+        for j in range(k):
+            want = port.multi_exp(curve, group, bl[j], sl[j], port.BDLO12_SIGNED, 1, chunks=4, omp=True)
+            if not (got[j] == want).all():
+                fails += 1
+                print(f"MISMATCH it={it} {name} n={n} k={k} j={j} c={c} form={form} endomorphism={eng.endomorphism}", flush=True)
+        if it % 25 == 0:
+            print(f"[fuzz batch] {it} cases, {fails} mismatches", flush=True)
     while args.mode == "multi_exp" and time.time() < t_end:
         name, curve, group = GROUPS[rng.integers(len(GROUPS))]
         heavy = group == 2 or curve == 2
