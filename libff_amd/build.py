@@ -24,7 +24,7 @@ GROUPS = ["alt_bn128_g1", "alt_bn128_g2", "bls12_377_g1", "bls12_377_g2", "bw6_7
 GROUP_FLAGS = {g: ["-DAMDMSM_HOT_INLINE=1", "-DAMDMSM_BENCH_BOTH=1"] for g in GROUPS}
 # register budget of the bucket-accumulation kernel: 4 waves per SIMD (128 VGPRs, 3 dwords of
 # scratch) instead of the 137 VGPRs / 3 waves the compiler picks unconstrained: -4 % at 2^20
-GROUP_FLAGS["alt_bn128_g1"] = GROUP_FLAGS["alt_bn128_g1"] + ["-DAMDMSM_ACC_WAVES=4"]
+# (superseded by the reduced-radix loop below, which is built for three)
 # overlap mode (several MSMs in flight: the tail of one under the sort and accumulation of the next, engine.cpp
 # amdmsm_ctx::bulk_stream): the tail kernels get the 128 registers three accumulation waves leave of a SIMD
 GROUP_FLAGS["alt_bn128_g1"] = GROUP_FLAGS["alt_bn128_g1"] + ["-DAMDMSM_OVERLAP_OK=1", "-DAMDMSM_TAIL_WAVES=4"]
@@ -49,10 +49,13 @@ for _g in ("bls12_377_g2", "bls12_381_g2", "alt_bn128_g2"):
 GROUP_FLAGS["alt_bn128_g2"] = GROUP_FLAGS["alt_bn128_g2"] + ["-DAMDMSM_ACC_WAVES=3"]
 for _g in ("bls12_377_g1", "bls12_381_g1"):
     GROUP_FLAGS[_g] = GROUP_FLAGS[_g] + ["-DAMDMSM_ACC_WAVES=3"]
+# k_accumulate on reduced-radix limbs (rr.cuh: 29-bit signed limbs, one v_mad_i64_i32 per limb product and no
+# carry instruction behind it): 168 registers at three waves per SIMD (later flags win over the 4 above)
+GROUP_FLAGS["alt_bn128_g1"] = GROUP_FLAGS["alt_bn128_g1"] + ["-DAMDMSM_ACC_RR=1", "-DAMDMSM_ACC_WAVES=3"]
 ARCH = "gfx950"
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-I" + INCLUDE, "-I" + CSRC,
           "-Wno-unused-result"]
-DEVICE_DEPS = ["msm_group.hip", "fp.cuh", "fp2.cuh", "fp2h.cuh", "ec.cuh", "wide.cuh", "wide28.cuh", "mac_chain.inc", "curve_params.h", "group_vtable.h", os.path.join(HERE, "build.py")]
+DEVICE_DEPS = ["msm_group.hip", "rr.cuh", "fp.cuh", "fp2.cuh", "fp2h.cuh", "ec.cuh", "wide.cuh", "wide28.cuh", "mac_chain.inc", "curve_params.h", "group_vtable.h", os.path.join(HERE, "build.py")]
 HOST_DEPS = ["engine.cpp", "ffi.cpp", "engine_internal.h", "group_vtable.h", os.path.join(INCLUDE, "amdmsm.h"),
              os.path.join(INCLUDE, "libff_amd_ffi.h")]
 

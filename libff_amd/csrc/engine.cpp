@@ -347,7 +347,7 @@ int make_plan(const group_vtable *vt, size_t n, int c_req, int L_req, plan_t &p,
     off = align_up(off + Wt * p.B * 4, 256);
     p.off_lists = off;
     off = align_up(off + Wt * p.list_stride * 4, 256);
-    const size_t zz_bytes = (size_t)4 * vt->el_words * 4;   // (X, Y, ZZ, ZZZ) bucket accumulators
+    const size_t zz_bytes = (size_t)vt->bucket_words * 4;   // (X, Y, ZZ, ZZZ) bucket accumulators (reduced-radix groups: 4 L limbs)
     p.off_buckets = off;
     off = align_up(off + Wt * p.B * zz_bytes, 256);
     const size_t M = p.B / p.L;
@@ -598,7 +598,7 @@ int msm_device_impl(amdmsm_ctx *ctx, const group_vtable *vt, const uint32_t *d_b
     // for the previous MSM's tail -- seen in a kernel trace: the accumulation then started only after that tail)
     hipStream_t side = overlap ? st : sl.side[0];
     if (!overlap) HIP_TRY(ctx, hipStreamWaitEvent(side, sl.tail_done[0], 0));
-    HIP_TRY(ctx, hipMemsetAsync(buckets, 0, (size_t)p.W * p.B * vt->el_words * 16, side));
+    HIP_TRY(ctx, hipMemsetAsync(buckets, 0, (size_t)p.W * p.B * vt->bucket_words * 4, side));
     for (int g = 0; g < p.G; ++g) HIP_TRY(ctx, hipMemsetAsync(ws + p.off_queue + g * p.queue_stride, 0, 8, side));
     if (endo_beside) vt->endo_points(side, d_bases, n, (uint32_t *)(ws + p.off_endo));
     if (!overlap) HIP_TRY(ctx, hipEventRecord(sl.acc_done[0], side));
@@ -610,7 +610,7 @@ int msm_device_impl(amdmsm_ctx *ctx, const group_vtable *vt, const uint32_t *d_b
     }
     if (!overlap) HIP_TRY(ctx, hipStreamWaitEvent(st, sl.acc_done[0], 0));
     if (glv && !d_endo_resident && !endo_beside) vt->endo_points(st, d_bases, n, (uint32_t *)(ws + p.off_endo));
-    const size_t zzw = (size_t)vt->el_words * 4, xyzw = (size_t)vt->el_words * 3;   // words per XYZZ / Jacobian point
+    const size_t zzw = (size_t)vt->bucket_words, xyzw = (size_t)vt->el_words * 3;   // words per XYZZ / Jacobian point
     const size_t M0 = p.B / p.L, cap1 = M0 / 2 + 1;
     uint32_t *pfirst = (uint32_t *)(ws + p.off_pfirst), *plast = (uint32_t *)(ws + p.off_plast);
     uint32_t *cont = (uint32_t *)(ws + p.off_cont), *partial = (uint32_t *)(ws + p.off_partial);
@@ -711,7 +711,7 @@ int msm_device_batch_impl(amdmsm_ctx *ctx, const group_vtable *vt, int k, const 
     rc = ensure_ws(ctx, sl, p.total);
     if (rc) return rc;
     char *ws = (char *)sl.ws;
-    const size_t zzw = (size_t)vt->el_words * 4, xyzw = (size_t)vt->el_words * 3;
+    const size_t zzw = (size_t)vt->bucket_words, xyzw = (size_t)vt->el_words * 3;
     const size_t Wt = (size_t)p.W * (size_t)k;
     uint32_t *counts = (uint32_t *)(ws + p.off_counts), *lists = (uint32_t *)(ws + p.off_lists);
     uint32_t *buckets = (uint32_t *)(ws + p.off_buckets);
@@ -719,7 +719,7 @@ int msm_device_batch_impl(amdmsm_ctx *ctx, const group_vtable *vt, int k, const 
     record(ctx, sl, 0, st);
     HIP_TRY(ctx, hipMemsetAsync(ws + p.off_coarse, 0, Wt * 1025 * 4, st));
     for (int j = 0; j < k; ++j) HIP_TRY(ctx, hipMemsetAsync(ws + p.off_big + (size_t)j * p.big_stride, 0, 16, st));
-    HIP_TRY(ctx, hipMemsetAsync(buckets, 0, Wt * p.B * vt->el_words * 16, st));
+    HIP_TRY(ctx, hipMemsetAsync(buckets, 0, Wt * p.B * vt->bucket_words * 4, st));
     HIP_TRY(ctx, hipMemsetAsync(ws + p.off_queue, 0, 8, st));
     record(ctx, sl, 1, st);
     for (int j = 0; j < k; ++j) {

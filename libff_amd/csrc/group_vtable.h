@@ -67,6 +67,7 @@ struct group_vtable {
     int fr_bits;       // bit length of the scalar-field modulus
     int projective;    // libff stores this group in homogeneous projective coordinates
     int reduce_fold;   // segments / points one wave of reduce_segments / sum_butterfly folds (64 or 32)
+    int bucket_words;  // words between two records of the bucket / partial accumulator arrays (>= 4 * el_words)
     const uint32_t* fr_one_mont;   // Fr::one() in Montgomery form (R mod r), fr_words words
     // endomorphism split k = k1 + k2 lambda (mod r), phi(x, y) = (beta x, y) = [lambda](x, y) on the
     // order-r subgroup (msm_group.hip glv_split): |k1|, |k2| <= 2^(glv_bound_log2_x1000 / 1000)

@@ -28,6 +28,7 @@
 #include "group_vtable.h"
 #include "wide.cuh"
 #include "wide28.cuh"
+#include "rr.cuh"
 
 #include <algorithm>
 #include <cstdio>
@@ -104,6 +105,20 @@ constexpr int EW = FQ::N * GP::DEG;   // words per coordinate
 constexpr int AFFW = 2 * EW;          // words per compact affine point
 constexpr int XYZW = 3 * EW;          // words per (X, Y, Z) record
 constexpr int ZZW = 4 * EW;           // words per (X, Y, ZZ, ZZZ) bucket accumulator
+// AMDMSM_ACC_RR (prime-field groups): k_accumulate keeps its accumulators on reduced-radix limbs (rr.cuh) and
+// writes them as they are -- 4 L words per record; k_rr_export rewrites every record in place as canonical
+// (X, Y, ZZ, ZZZ) words before any other kernel reads it.  ZZS = words between two records of the bucket /
+// partial arrays (group_vtable::bucket_words).
+#ifndef AMDMSM_ACC_RR
+#define AMDMSM_ACC_RR 0
+#endif
+#if AMDMSM_ACC_RR
+static_assert(GP::DEG == 1 && !AMDMSM_ACC_SPLIT, "reduced-radix accumulation is built for prime fields");
+constexpr int RRL = rr_shape<FQ>::L;
+constexpr int ZZS = 4 * RRL;
+#else
+constexpr int ZZS = ZZW;
+#endif
 constexpr int FRW = FR::N;            // words per scalar
 constexpr int TPB = 256;
 
@@ -938,6 +953,62 @@ __global__ void __launch_bounds__(SORT_TPB) k_sort_big_scatter(const uint32_t* _
 // k_accumulate_fixup then closes every spanning bucket:
 //   bucket = part_last[t] + part_first[t+1] + ... + part_first[lane of its last entry].
 // buckets[] is zero-filled beforehand, so untouched (empty) buckets read as infinity.
+// The accumulator of one lane of k_accumulate and what it does with it: XYZZ on almost-reduced 32-bit words
+// (ec.cuh xyzz_madd_lz) or, for AMDMSM_ACC_RR groups, on reduced-radix limbs (rr.cuh xyzz_madd_rr: no carry
+// instruction behind a multiply, limb-wise linear operations, an infinity flag instead of a zero test).
+#if AMDMSM_ACC_RR
+struct acc_state {
+    XyzzRr<FQ> a;
+    bool inf;
+};
+AMDMSM_DEV void acc_reset(acc_state& s) { s.inf = true; }   // the limbs are dead while inf is set
+// the record as it is: 4 L limbs (all zero: infinity); k_rr_export makes canonical words of it
+AMDMSM_DEV void acc_store(uint32_t* q, const acc_state& s) {
+    const int32_t keep = s.inf ? 0 : -1;
+    uint32_t w[ZZS];
+#pragma unroll
+    for (int i = 0; i < RRL; ++i) {
+        w[i] = (uint32_t)(s.a.x.v[i] & keep);
+        w[RRL + i] = (uint32_t)(s.a.y.v[i] & keep);
+        w[2 * RRL + i] = (uint32_t)(s.a.zz.v[i] & keep);
+        w[3 * RRL + i] = (uint32_t)(s.a.zzz.v[i] & keep);
+    }
+    uint4* q4 = reinterpret_cast<uint4*>(q);
+#pragma unroll
+    for (int i = 0; i < ZZS / 4; ++i) q4[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
+AMDMSM_DEV void acc_add(acc_state& s, const uint32_t* rec, bool neg) {
+    uint32_t wx[FQ::N], wy[FQ::N];
+    const uint4* r4 = reinterpret_cast<const uint4*>(rec);
+#pragma unroll
+    for (int i = 0; i < FQ::N / 4; ++i) {
+        const uint4 a = r4[i], b = r4[FQ::N / 4 + i];
+        wx[4 * i] = a.x; wx[4 * i + 1] = a.y; wx[4 * i + 2] = a.z; wx[4 * i + 3] = a.w;
+        wy[4 * i] = b.x; wy[4 * i + 1] = b.y; wy[4 * i + 2] = b.z; wy[4 * i + 3] = b.w;
+    }
+    xyzz_madd_rr<FQ>(s.a, s.inf, wx, wy, neg);
+}
+#else
+struct acc_state {
+    Xyzz<EA> a;
+};
+AMDMSM_DEV void acc_reset(acc_state& s) { xyzz_set_inf(s.a); }
+AMDMSM_DEV void acc_store(uint32_t* q, acc_state& s) {
+    xyzz_canon(s.a);
+    store_xyzz(q, s.a);
+}
+AMDMSM_DEV void acc_add(acc_state& s, const uint32_t* rec, bool neg) {
+    Aff<EA> p;
+    load_aff(p, rec);
+    el_cneg(p.y, p.y, neg);   // -(x, y) = (x, -y); (0,0) stays infinity
+#if AMDMSM_ACC_LAZY
+    xyzz_madd_lz(s.a, p);   // coordinates of acc stay in [0, 2p) between stores
+#else
+    xyzz_madd(s.a, p);
+#endif
+}
+#endif
+
 constexpr uint32_t NO_BUCKET = 0xffffffffu;
 
 // smallest b with e[b] > k   (e non-decreasing, e[B-1] > k)
@@ -999,9 +1070,9 @@ __global__ void __launch_bounds__(TPB, AMDMSM_ACC_WAVES) k_accumulate(const uint
     uint32_t bnext = b + 1 < B ? e[b + 1] : 0xffffffffu;
     bool from_prev = (b ? e[b - 1] : 0u) < lo;   // first piece continues a bucket begun earlier
     const uint32_t* lst = lists + w * list_stride;
-    uint32_t* bk = buckets + w * (size_t)B * ZZW;
-    Xyzz<EA> acc;
-    xyzz_set_inf(acc);
+    uint32_t* bk = buckets + w * (size_t)B * ZZS;
+    acc_state acc;
+    acc_reset(acc);
     // The lane's list entries are staged through LDS sixteen at a time (sixteen loads issued
     // together, once per sixteen iterations): read one word per iteration, the 256 lanes of a
     // workgroup touch 256 different cache lines every iteration, the point gathers evict them in
@@ -1055,10 +1126,9 @@ __global__ void __launch_bounds__(TPB, AMDMSM_ACC_WAVES) k_accumulate(const uint
         }
         if (k == bend) {
             // bucket b ends here: it is complete unless its head lies in an earlier lane
-            xyzz_canon(acc);
-            store_xyzz(from_prev ? part_first + g * ZZW : bk + (size_t)b * ZZW, acc);
+            acc_store(from_prev ? part_first + g * ZZS : bk + (size_t)b * ZZS, acc);
             from_prev = false;
-            xyzz_set_inf(acc);
+            acc_reset(acc);
             do {
                 ++b;
                 bend = bnext;
@@ -1073,27 +1143,55 @@ __global__ void __launch_bounds__(TPB, AMDMSM_ACC_WAVES) k_accumulate(const uint
 #else
         const uint32_t pi = ent & 0x7fffffffu;
 #endif
-        Aff<EA> p;
-        load_aff(p, pi >= n_real ? endo_pts + (size_t)(pi - n_real) * AFFW : bases + (size_t)pi * AFFW);
-        el_cneg(p.y, p.y, (ent >> 31) != 0);   // -(x, y) = (x, -y); (0,0) stays infinity
-#if AMDMSM_ACC_LAZY
-        xyzz_madd_lz(acc, p);   // coordinates of acc stay in [0, 2p) between stores
-#else
-        xyzz_madd(acc, p);
-#endif
+        acc_add(acc, pi >= n_real ? endo_pts + (size_t)(pi - n_real) * AFFW : bases + (size_t)pi * AFFW, (ent >> 31) != 0);
     }
-    xyzz_canon(acc);
     if (bend == hi) {   // the last bucket ends exactly with the lane
-        store_xyzz(from_prev ? part_first + g * ZZW : bk + (size_t)b * ZZW, acc);
+        acc_store(from_prev ? part_first + g * ZZS : bk + (size_t)b * ZZS, acc);
         cont_bucket[g] = NO_BUCKET;
     } else if (from_prev) {   // the whole lane lies inside one bucket
-        store_xyzz(part_first + g * ZZW, acc);
+        acc_store(part_first + g * ZZS, acc);
         cont_bucket[g] = NO_BUCKET;
     } else {   // bucket b starts in this lane and continues
-        store_xyzz(part_last + g * ZZW, acc);
+        acc_store(part_last + g * ZZS, acc);
         cont_bucket[g] = b;
     }
 }
+
+#if AMDMSM_ACC_RR
+// Every record k_accumulate wrote (buckets, part_first, part_last: 4 L reduced-radix limbs each, ZZS words apart)
+// becomes canonical (X, Y, ZZ, ZZZ) words at the start of the same record.  Records nobody wrote hold zeros
+// (buckets: infinity) or leftovers (partials the fix-up does not look at): both pass through harmlessly.
+__global__ void __launch_bounds__(TPB) k_rr_export(uint32_t* __restrict__ buckets, size_t n_buckets, uint32_t* __restrict__ part_first,
+                                                   uint32_t* __restrict__ part_last, size_t n_lanes) {
+    const size_t i = gtid();
+    if (i >= n_buckets + 2 * n_lanes) return;
+    uint32_t* q = i < n_buckets ? buckets + i * ZZS
+                                : (i < n_buckets + n_lanes ? part_first + (i - n_buckets) * ZZS : part_last + (i - n_buckets - n_lanes) * ZZS);
+    uint32_t w[ZZS];
+    const uint4* q4 = reinterpret_cast<const uint4*>(q);
+    uint32_t any = 0;
+#pragma unroll
+    for (int k = 0; k < ZZS / 4; ++k) {
+        const uint4 v = q4[k];
+        w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
+        any |= v.x | v.y | v.z | v.w;
+    }
+    if (any == 0) return;
+    XyzzRr<FQ> a;
+#pragma unroll
+    for (int k = 0; k < RRL; ++k) {
+        a.x.v[k] = (int32_t)w[k];
+        a.y.v[k] = (int32_t)w[RRL + k];
+        a.zz.v[k] = (int32_t)w[2 * RRL + k];
+        a.zzz.v[k] = (int32_t)w[3 * RRL + k];
+    }
+    uint32_t out[ZZW];
+    xyzz_rr_export<FQ>(out, a);
+    uint4* o4 = reinterpret_cast<uint4*>(q);
+#pragma unroll
+    for (int k = 0; k < ZZW / 4; ++k) o4[k] = make_uint4(out[4 * k], out[4 * k + 1], out[4 * k + 2], out[4 * k + 3]);
+}
+#endif
 
 AMDMSM_DEV void wave_group_sum(Jac<E>& p, uint32_t G);
 AMDMSM_DEV void wave_group_sum_r(Jac<ER>& p, uint32_t G);
@@ -1159,14 +1257,14 @@ __global__ void __launch_bounds__(64) k_accumulate_fixup(const uint32_t* __restr
     }
     if (span == 0 || span > INLINE_SPAN) return;
     Xyzz<ER> acc, x;
-    load_xyzz(acc, part_last + g * ZZW);
+    load_xyzz(acc, part_last + g * ZZS);
 #ifndef AMDMSM_FIX_PRIO
 #define AMDMSM_FIX_PRIO 1
 #endif
     // priority falling with progress, as in k_accumulate: the waves of a SIMD end together
     if (AMDMSM_FIX_PRIO) __builtin_amdgcn_s_setprio(3);
     for (uint32_t u = t + 1; u <= t_last; ++u) {
-        load_xyzz(x, part_first + (w * T + u) * ZZW);
+        load_xyzz(x, part_first + (w * T + u) * ZZS);
         xyzz_add(acc, acc, x);
         if (AMDMSM_FIX_PRIO) {
             const uint32_t done = (uint32_t)__builtin_amdgcn_readfirstlane((int)(u - t));
@@ -1175,7 +1273,7 @@ __global__ void __launch_bounds__(64) k_accumulate_fixup(const uint32_t* __restr
             if (done >= 3) __builtin_amdgcn_s_setprio(0);
         }
     }
-    store_xyzz(buckets + (w * B + b) * ZZW, acc);
+    store_xyzz(buckets + (w * B + b) * ZZS, acc);
 }
 
 // A bucket that spans thousands of lanes (one scalar value repeated across much of the input)
@@ -1203,14 +1301,14 @@ __global__ void __launch_bounds__(64) k_accumulate_compact(const uint32_t* __res
     Xyzz<ER> acc, x;
     xyzz_set_inf(acc);
     for (uint32_t u = first + lane; u <= last; u += RED_FOLD) {
-        load_xyzz(x, part_first + (w * T + u) * ZZW);
+        load_xyzz(x, part_first + (w * T + u) * ZZS);
         xyzz_add(acc, acc, x);
     }
     Jac<ER> j;
     xyzz_to_jac(j, acc);
     wave_group_sum_r(j, RED_FOLD);
     jac_to_xyzz(acc, j);
-    if (lane == 0) store_xyzz(part_first + (w * T + first) * ZZW, acc);
+    if (lane == 0) store_xyzz(part_first + (w * T + first) * ZZS, acc);
 }
 
 // G lanes per queued bucket (G = 64 for the long queue, MID_G for the mid queue): the lanes
@@ -1248,7 +1346,7 @@ __global__ void __launch_bounds__(64, AMDMSM_TAIL_WAVES) k_accumulate_fixup_queu
             const uint32_t t = (uint32_t)(g % T);
             b = cont_bucket[g];
             const uint32_t t_last = (ends[w * B + b] - 1) / S;
-            if (lane == 0) load_xyzz(acc, part_last + g * ZZW);
+            if (lane == 0) load_xyzz(acc, part_last + g * ZZS);
             // lanes t+1 .. t_last = head [t+1, h), nb folded blocks from h, tail [tail0, t_last]
             uint32_t h = (t + 1 + FIX_BLOCK - 1) / FIX_BLOCK * FIX_BLOCK;
             uint32_t nb = 0;
@@ -1257,7 +1355,7 @@ __global__ void __launch_bounds__(64, AMDMSM_TAIL_WAVES) k_accumulate_fixup_queu
             const uint32_t items = nh + nb + (t_last + 1 - tail0);
             for (uint32_t i = lane; i < items; i += G) {
                 const uint32_t u = i < nh ? t + 1 + i : (i < nh + nb ? h + (i - nh) * FIX_BLOCK : tail0 + (i - nh - nb));
-                load_xyzz(x, part_first + (w * T + u) * ZZW);
+                load_xyzz(x, part_first + (w * T + u) * ZZS);
                 xyzz_add(acc, acc, x);
             }
         }
@@ -1265,7 +1363,7 @@ __global__ void __launch_bounds__(64, AMDMSM_TAIL_WAVES) k_accumulate_fixup_queu
         xyzz_to_jac(j, acc);
         wave_group_sum_r(j, G);
         jac_to_xyzz(acc, j);
-        if (live && lane == 0) store_xyzz(buckets + (w * B + b) * ZZW, acc);
+        if (live && lane == 0) store_xyzz(buckets + (w * B + b) * ZZS, acc);
     }
 }
 
@@ -1307,12 +1405,12 @@ __global__ void __launch_bounds__(64) k_reduce_segments(const uint32_t* __restri
     jac_set_inf(acc);
     jac_set_inf(sum);
     if (valid) {
-        const uint32_t* seg = buckets + (w * B + (size_t)s * L) * ZZW;
+        const uint32_t* seg = buckets + (w * B + (size_t)s * L) * ZZS;
         Xyzz<ER> xa, xs, xb;
         xyzz_set_inf(xa);
         xyzz_set_inf(xs);
         for (uint32_t j = L; j-- > 0;) {
-            load_xyzz(xb, seg + (size_t)j * ZZW);
+            load_xyzz(xb, seg + (size_t)j * ZZS);
             xyzz_add(xa, xa, xb);    // xa = sum_{k >= j} B_k
             xyzz_add(xs, xs, xa);    // xs = sum_k (k - j + 1) B_k
         }
@@ -1455,12 +1553,12 @@ __global__ void __launch_bounds__(64, AMDMSM_TAIL_WAVES) k_bucket_sums(const uin
     Xyzz<ER> xa, xb;
     xyzz_set_inf(xa);
     if (valid) {
-        const uint32_t* bk = buckets + w * (size_t)B * ZZW;
+        const uint32_t* bk = buckets + w * (size_t)B * ZZS;
         for (uint32_t i = 0; i < q; ++i) {
             const uint32_t idx = j * q + i;
             const uint64_t b1 = col ? (uint64_t)idx * C + o : (uint64_t)o * C + idx;   // weight b + 1
             if (b1 >= 1 && b1 <= B) {
-                load_xyzz(xb, bk + (size_t)(b1 - 1) * ZZW);
+                load_xyzz(xb, bk + (size_t)(b1 - 1) * ZZS);
                 xyzz_add(xa, xa, xb);
             }
         }
@@ -2453,6 +2551,10 @@ void l_accumulate(hipStream_t st, const uint32_t* ends, const uint32_t* lists, s
                        list_stride, bases, buckets, part_first, part_last, cont_bucket, W, B, S, T, endo_pts,
                        endo_pts ? (uint32_t)n_real : 0x80000000u, sync_waves);
 #endif
+#if AMDMSM_ACC_RR
+    hipLaunchKernelGGL(k_rr_export, dim3(blocks_for((size_t)W * B + 2 * (size_t)W * T)), dim3(TPB), 0, st, buckets, (size_t)W * B,
+                       part_first, part_last, (size_t)W * T);
+#endif
 }
 void l_endo_points(hipStream_t st, const uint32_t* bases, size_t n, uint32_t* out) {
     if (!n) return;
@@ -2633,7 +2735,7 @@ void l_madd_bench(hipStream_t st, const uint32_t* pts, uint32_t* out, size_t nth
 }
 
 const group_vtable g_vt = {
-    GP::CURVE, GP::GROUP, FRW, EW, FQ::N, FR::BITS, GP::LIBFF_PROJECTIVE ? 1 : 0, (int)RED_FOLD, FR::R,
+    GP::CURVE, GP::GROUP, FRW, EW, FQ::N, FR::BITS, GP::LIBFF_PROJECTIVE ? 1 : 0, (int)RED_FOLD, ZZS, FR::R,
     GLV::BOUND_LOG2_X1000, GP::SUBGROUP_CHECK == 0 ? 1 : 0, GLV::LAMBDA, l_endo_points, l_glv_digits,
     l_import_bases, l_precompute_table, l_count, l_scatter, l_scalar_stats, l_sort, l_accumulate, l_accumulate_resident_lanes, (AMDMSM_OVERLAP_OK && ACC_OVERLAP_LDS) ? 1 : 0, l_accumulate_fixup, l_reduce_segments, l_sum_butterfly, l_sum_block, l_reduce_rowcol, l_horner, l_horner_batch, l_sum_points,
     l_gen_bases_seq, l_export_affine, l_ffi_decode_points, l_ffi_decode_scalars, l_ffi_encode_point, l_disk_decode, l_disk_decode_compressed, l_fixed_base_exp, l_field_op, l_group_op, l_digits, l_mul_bench, l_madd_bench,

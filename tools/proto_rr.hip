@@ -1,0 +1,184 @@
+// Prototype / self-test: XYZZ mixed addition on reduced-radix limbs (rr.cuh: 28/29-bit signed limbs,
+// v_mad_i64_i32 columns without carry instructions) against the 32-bit form of k_accumulate
+// (xyzz_madd_lz, ec.cuh).  Checks that both give the same canonical accumulator on random field
+// elements (the formulas are polynomial identities: the inputs need not lie on the curve), including
+// the equal-point / opposite-point / infinity cases, then times the two loops.
+//   hipcc -O3 --offload-arch=gfx950 -std=c++17 -Ilibff_amd/csrc tools/proto_rr.hip -o gpurun_out/proto_rr
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "curve_params.h"
+#include "ec.cuh"
+#include "rr.cuh"
+
+using namespace amdmsm;
+
+template <class P>
+__global__ void __launch_bounds__(256) k_check(const uint32_t* __restrict__ pts, size_t npts, int len, uint32_t* out32,
+                                               uint32_t* outrr) {
+    constexpr int N = P::N;
+    using F = Fp<P, true>;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    Xyzz<F> a;
+    xyzz_set_inf(a);
+    XyzzRr<P> b;
+    rr_zero(b.x); rr_zero(b.y); rr_zero(b.zz); rr_zero(b.zzz);
+    bool inf = true;
+    for (int k = 0; k < len; ++k) {
+        // pattern per lane: mostly distinct points; lane % 8 == 1: every point twice (doubling);
+        // lane % 8 == 2: point then its negative (infinity, then restart); lane % 8 == 3: an infinity in between
+        size_t idx = (i * 131 + (size_t)k * 7) % npts;
+        bool neg = ((i + k) & 1) != 0;
+        const int mode = (int)(i % 8);
+        if (mode == 1) { idx = (i * 131 + (size_t)(k / 2) * 7) % npts; neg = false; }
+        if (mode == 2) { idx = (i * 131 + (size_t)(k / 2) * 7) % npts; neg = (k & 1) != 0; }
+        uint32_t wx[N], wy[N];
+        for (int j = 0; j < N; ++j) { wx[j] = pts[idx * 2 * N + j]; wy[j] = pts[idx * 2 * N + N + j]; }
+        if (mode == 3 && k % 3 == 1) { for (int j = 0; j < N; ++j) wx[j] = wy[j] = 0; }
+        Aff<F> p;
+        for (int j = 0; j < N; ++j) { p.x.v[j] = wx[j]; p.y.v[j] = wy[j]; }
+        fp_cneg(p.y, p.y, neg);
+        xyzz_madd_lz(a, p);
+        xyzz_madd_rr<P>(b, inf, wx, wy, neg);
+    }
+    xyzz_canon(a);
+    for (int j = 0; j < N; ++j) {
+        out32[i * 4 * N + j] = a.x.v[j];
+        out32[i * 4 * N + N + j] = a.y.v[j];
+        out32[i * 4 * N + 2 * N + j] = a.zz.v[j];
+        out32[i * 4 * N + 3 * N + j] = a.zzz.v[j];
+    }
+    uint32_t w[4 * N];
+    if (inf) { rr_zero(b.x); rr_zero(b.y); rr_zero(b.zz); rr_zero(b.zzz); }
+    xyzz_rr_export<P>(w, b);
+    for (int j = 0; j < 4 * N; ++j) outrr[i * 4 * N + j] = w[j];
+}
+
+template <class P, int WAVES>
+__global__ void __launch_bounds__(256, WAVES) k_time32(const uint32_t* __restrict__ pts, size_t npts, int len, uint32_t* out) {
+    constexpr int N = P::N;
+    using F = Fp<P, true>;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    Xyzz<F> a;
+    xyzz_set_inf(a);
+    for (int k = 0; k < len; ++k) {
+        const size_t idx = (i * 131 + (size_t)k * 7) % npts;
+        Aff<F> p;
+        fp_load(p.x, pts + idx * 2 * N);
+        fp_load(p.y, pts + idx * 2 * N + N);
+        fp_cneg(p.y, p.y, ((i + k) & 1) != 0);
+        xyzz_madd_lz(a, p);
+    }
+    xyzz_canon(a);
+    uint32_t x = 0;
+    for (int j = 0; j < N; ++j) x ^= a.x.v[j] ^ a.y.v[j] ^ a.zz.v[j] ^ a.zzz.v[j];
+    out[i] = x;
+}
+
+template <class P, int WAVES>
+__global__ void __launch_bounds__(256, WAVES) k_timerr(const uint32_t* __restrict__ pts, size_t npts, int len, uint32_t* out) {
+    constexpr int N = P::N;
+    constexpr int L = rr_shape<P>::L;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    XyzzRr<P> b;
+    rr_zero(b.x); rr_zero(b.y); rr_zero(b.zz); rr_zero(b.zzz);
+    bool inf = true;
+    for (int k = 0; k < len; ++k) {
+        const size_t idx = (i * 131 + (size_t)k * 7) % npts;
+        uint32_t wx[N], wy[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) { wx[j] = pts[idx * 2 * N + j]; wy[j] = pts[idx * 2 * N + N + j]; }
+        xyzz_madd_rr<P>(b, inf, wx, wy, ((i + k) & 1) != 0);
+    }
+    uint32_t x = inf;
+    for (int j = 0; j < L; ++j) x ^= (uint32_t)(b.x.v[j] ^ b.y.v[j] ^ b.zz.v[j] ^ b.zzz.v[j]);
+    out[i] = x;
+}
+
+template <class P, int W32, int WRR>
+int run(const char* name) {
+    constexpr int N = P::N;
+    const size_t npts = 1 << 16;
+    std::vector<uint32_t> h(npts * 2 * N);
+    uint64_t st = 0x9e3779b97f4a7c15ull;
+    for (size_t i = 0; i < h.size(); ++i) {
+        st = st * 6364136223846793005ull + 1442695040888963407ull;
+        h[i] = (uint32_t)(st >> 32);
+        if (i % N == (size_t)N - 1) h[i] %= P::P[N - 1];   // below p
+    }
+    uint32_t *dp, *o32, *orr;
+    const size_t lanes = 4096;
+    hipMalloc(&dp, h.size() * 4);
+    hipMalloc(&o32, lanes * 4 * N * 4);
+    hipMalloc(&orr, lanes * 4 * N * 4);
+    hipMemcpy(dp, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+    int bad = 0;
+    for (int len : {1, 2, 3, 4, 7, 24}) {
+        hipLaunchKernelGGL(k_check<P>, dim3(lanes / 256), dim3(256), 0, 0, dp, npts, len, o32, orr);
+        std::vector<uint32_t> a(lanes * 4 * N), b(lanes * 4 * N);
+        hipMemcpy(a.data(), o32, a.size() * 4, hipMemcpyDeviceToHost);
+        hipMemcpy(b.data(), orr, b.size() * 4, hipMemcpyDeviceToHost);
+        int mism = 0;
+        for (size_t i = 0; i < lanes; ++i) {
+            // compare as projective XYZZ points would be too weak: both follow the same formulas, so words must agree
+            bool eq = true;
+            for (int j = 0; j < 4 * N; ++j) eq &= a[i * 4 * N + j] == b[i * 4 * N + j];
+            if (!eq) {
+                if (mism < 3) {
+                    printf("  mismatch lane %zu (mode %zu) len %d\n   32: ", i, i % 8, len);
+                    for (int j = 0; j < 4 * N; ++j) printf("%08x ", a[i * 4 * N + j]);
+                    printf("\n   rr: ");
+                    for (int j = 0; j < 4 * N; ++j) printf("%08x ", b[i * 4 * N + j]);
+                    printf("\n");
+                }
+                ++mism;
+            }
+        }
+        printf("%s: len %2d: %d mismatches of %zu lanes\n", name, len, mism, lanes);
+        bad += mism;
+    }
+    // timing: one round of resident waves at the kernel's occupancy
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    uint32_t* dout;
+    const size_t tl32 = (size_t)256 * 4 * W32 * 64, tlrr = (size_t)256 * 4 * WRR * 64;
+    hipMalloc(&dout, (tl32 > tlrr ? tl32 : tlrr) * 4);
+    const int len = N <= 8 ? 256 : (N <= 12 ? 128 : 32);
+    for (int rep = 0; rep < 3; ++rep) {
+        float ms32 = 0, msrr = 0;
+        hipEventRecord(e0);
+        hipLaunchKernelGGL((k_time32<P, W32>), dim3(tl32 / 256), dim3(256), 0, 0, dp, npts, len, dout);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms32, e0, e1);
+        hipEventRecord(e0);
+        hipLaunchKernelGGL((k_timerr<P, WRR>), dim3(tlrr / 256), dim3(256), 0, 0, dp, npts, len, dout);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        hipEventElapsedTime(&msrr, e0, e1);
+        printf("%s: 32-bit words (%d waves/SIMD) %8.3f ms %7.2f G madd/s | reduced radix (%d waves/SIMD) %8.3f ms %7.2f G madd/s | ratio %.3f\n",
+               name, W32, ms32, (double)tl32 * len / ms32 / 1e6, WRR, msrr, (double)tlrr * len / msrr / 1e6,
+               ((double)tlrr / msrr) / ((double)tl32 / ms32));
+    }
+    return bad;
+}
+
+int main(int argc, char** argv) {
+    int bad = 0;
+    const char* which = argc > 1 ? argv[1] : "all";
+    const bool all = std::string(which) == "all";
+#ifndef PROTO_ONLY_ALT
+    if (all || std::string(which) == "bls12_377") bad += run<bls12_377_fq, 3, 3>("bls12_377 Fq");
+    if (all || std::string(which) == "bls12_377") bad += run<bls12_377_fq, 3, 2>("bls12_377 Fq");
+    if (all || std::string(which) == "bw6_761") bad += run<bw6_761_fq, 2, 2>("bw6_761 Fq");
+#endif
+    if (all || std::string(which) == "alt_bn128") bad += run<alt_bn128_fq, 4, 4>("alt_bn128 Fq");
+    if (all || std::string(which) == "alt_bn128") bad += run<alt_bn128_fq, 4, 3>("alt_bn128 Fq");
+    printf(bad ? "FAILED\n" : "all equal\n");
+    return bad != 0;
+}
