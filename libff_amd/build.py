@@ -49,13 +49,16 @@ for _g in ("bls12_377_g2", "bls12_381_g2", "alt_bn128_g2"):
 GROUP_FLAGS["alt_bn128_g2"] = GROUP_FLAGS["alt_bn128_g2"] + ["-DAMDMSM_ACC_WAVES=3"]
 for _g in ("bls12_377_g1", "bls12_381_g1"):
     GROUP_FLAGS[_g] = GROUP_FLAGS[_g] + ["-DAMDMSM_ACC_WAVES=3"]
-# k_accumulate on reduced-radix limbs (rr.cuh: 29-bit signed limbs, one v_mad_i64_i32 per limb product and no
-# carry instruction behind it): 168 registers at three waves per SIMD (later flags win over the 4 above)
-GROUP_FLAGS["alt_bn128_g1"] = GROUP_FLAGS["alt_bn128_g1"] + ["-DAMDMSM_ACC_RR=1", "-DAMDMSM_ACC_WAVES=3"]
+# k_accumulate on reduced-radix limbs for the prime-field groups (rr.cuh: 28 / 29-bit signed limbs, one
+# v_mad_i64_i32 per limb product and no carry instruction behind it, limb-wise linear operations): 1.3x the
+# mixed additions per second of the 32-bit loop on every field (tools/proto_rr.hip).  Register budget: three
+# waves per SIMD for the 9-limb field (134 registers), two for 14 and 28 limbs.
+for _g, _w in (("alt_bn128_g1", 3), ("bls12_377_g1", 2), ("bls12_381_g1", 2), ("bw6_761_g1", 2), ("bw6_761_g2", 2)):
+    GROUP_FLAGS[_g] = [f for f in GROUP_FLAGS[_g] if not f.startswith("-DAMDMSM_ACC_WAVES=")] + ["-DAMDMSM_ACC_RR=1", f"-DAMDMSM_ACC_WAVES={_w}"]
 ARCH = "gfx950"
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-I" + INCLUDE, "-I" + CSRC,
           "-Wno-unused-result"]
-DEVICE_DEPS = ["msm_group.hip", "rr.cuh", "fp.cuh", "fp2.cuh", "fp2h.cuh", "ec.cuh", "wide.cuh", "wide28.cuh", "mac_chain.inc", "curve_params.h", "group_vtable.h", os.path.join(HERE, "build.py")]
+DEVICE_DEPS = ["msm_group.hip", "rr.cuh", "rr_chain.inc", "fp.cuh", "fp2.cuh", "fp2h.cuh", "ec.cuh", "wide.cuh", "wide28.cuh", "mac_chain.inc", "curve_params.h", "group_vtable.h", os.path.join(HERE, "build.py")]
 HOST_DEPS = ["engine.cpp", "ffi.cpp", "engine_internal.h", "group_vtable.h", os.path.join(INCLUDE, "amdmsm.h"),
              os.path.join(INCLUDE, "libff_amd_ffi.h")]
 

@@ -977,16 +977,18 @@ AMDMSM_DEV void acc_store(uint32_t* q, const acc_state& s) {
 #pragma unroll
     for (int i = 0; i < ZZS / 4; ++i) q4[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
 }
-AMDMSM_DEV void acc_add(acc_state& s, const uint32_t* rec, bool neg) {
-    uint32_t wx[FQ::N], wy[FQ::N];
+// one affine record (x, y) as words
+struct aff_words {
+    uint32_t x[FQ::N], y[FQ::N];
+};
+AMDMSM_DEV void aff_words_load(aff_words& p, const uint32_t* rec) {
     const uint4* r4 = reinterpret_cast<const uint4*>(rec);
 #pragma unroll
     for (int i = 0; i < FQ::N / 4; ++i) {
         const uint4 a = r4[i], b = r4[FQ::N / 4 + i];
-        wx[4 * i] = a.x; wx[4 * i + 1] = a.y; wx[4 * i + 2] = a.z; wx[4 * i + 3] = a.w;
-        wy[4 * i] = b.x; wy[4 * i + 1] = b.y; wy[4 * i + 2] = b.z; wy[4 * i + 3] = b.w;
+        p.x[4 * i] = a.x; p.x[4 * i + 1] = a.y; p.x[4 * i + 2] = a.z; p.x[4 * i + 3] = a.w;
+        p.y[4 * i] = b.x; p.y[4 * i + 1] = b.y; p.y[4 * i + 2] = b.z; p.y[4 * i + 3] = b.w;
     }
-    xyzz_madd_rr<FQ>(s.a, s.inf, wx, wy, neg);
 }
 #else
 struct acc_state {
@@ -1102,6 +1104,61 @@ __global__ void __launch_bounds__(TPB, AMDMSM_ACC_WAVES) k_accumulate(const uint
     if (sync_waves == 1) __builtin_amdgcn_s_setprio(3);
     if (sync_waves == 2) __builtin_amdgcn_s_setprio(2);
 #endif
+#if AMDMSM_ACC_RR
+    // The point of iteration k + 1 is fetched in the middle of iteration k (xyzz_madd_rr's mid hook): its words
+    // take the registers the limbs of point k leave, and the gather's latency lies under eight products instead
+    // of in front of the first one (three waves per SIMD do not cover it as four did for the 32-bit loop).
+    aff_words pw;
+    bool pneg = false;
+    auto stage = [&](uint32_t k0) {   // list entries k0 .. k0 + 15 of this lane into its LDS column
+        uint32_t v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = lst[k0 + q];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) staged[q * TPB + threadIdx.x] = v[q];
+    };
+    auto fetch = [&](uint32_t k1) {
+        const uint32_t ent = staged[((k1 - lo) & 15u) * TPB + threadIdx.x];
+        const uint32_t pi = ent & 0x7fffffffu;
+        aff_words_load(pw, pi >= n_real ? endo_pts + (size_t)(pi - n_real) * AFFW : bases + (size_t)pi * AFFW);
+        pneg = (ent >> 31) != 0;
+    };
+    stage(lo);
+    fetch(lo);
+    for (uint32_t k = lo; k < hi; ++k) {
+#if AMDMSM_ACC_PRIO
+        {
+            const uint32_t j = (uint32_t)__builtin_amdgcn_readfirstlane((int)(k - lo));
+            if (sync_waves == 1) {
+                if (j == mark1) __builtin_amdgcn_s_setprio(2);
+                if (j == mark2) __builtin_amdgcn_s_setprio(1);
+                if (j == mark3) __builtin_amdgcn_s_setprio(0);
+            } else {
+                if (j == mark1) __builtin_amdgcn_s_setprio(1);
+                if (j == mark2) __builtin_amdgcn_s_setprio(0);
+            }
+        }
+#endif
+        if (k == bend) {
+            // bucket b ends here: it is complete unless its head lies in an earlier lane
+            acc_store(from_prev ? part_first + g * ZZS : bk + (size_t)b * ZZS, acc);
+            from_prev = false;
+            acc_reset(acc);
+            do {
+                ++b;
+                bend = bnext;
+                bnext = b + 1 < B ? e[b + 1] : 0xffffffffu;
+            } while (bend == k);   // skip empty buckets (k < total = e[B-1] bounds the walk)
+        }
+        const bool neg = pneg;
+        xyzz_madd_rr<FQ>(acc.a, acc.inf, pw.x, pw.y, neg, [&] {
+            if (k + 1 < hi) {
+                if (((k + 1 - lo) & 15u) == 0) stage(k + 1);
+                fetch(k + 1);
+            }
+        });
+    }
+#else
     for (uint32_t k = lo; k < hi; ++k) {
 #if AMDMSM_ACC_PRIO
         {
@@ -1145,6 +1202,7 @@ __global__ void __launch_bounds__(TPB, AMDMSM_ACC_WAVES) k_accumulate(const uint
 #endif
         acc_add(acc, pi >= n_real ? endo_pts + (size_t)(pi - n_real) * AFFW : bases + (size_t)pi * AFFW, (ent >> 31) != 0);
     }
+#endif
     if (bend == hi) {   // the last bucket ends exactly with the lane
         acc_store(from_prev ? part_first + g * ZZS : bk + (size_t)b * ZZS, acc);
         cont_bucket[g] = NO_BUCKET;

@@ -114,30 +114,37 @@ struct Rr {
     int32_t v[L];
 };
 
-// ---- multiply-accumulate: acc += a * b (signed 32 x 32 + 64), one issue, carry-out unused ----
-AMDMSM_DEV void rr_mad_vv(int64_t& acc, int32_t a, int32_t b) {
-    uint64_t co;
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(co) : "v"(a), "v"(b));
-}
-AMDMSM_DEV void rr_mad_vs(int64_t& acc, int32_t a, int32_t b) {
-    uint64_t co;
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(co) : "v"(a), "s"(b));
-}
+// ---- multiply-accumulate chains: acc += sum a_i * b_i (signed 32 x 32 + 64 each, one issue, carry-out unused),
+// one asm statement per chain of up to RR_CHUNK products (tools/gen_rr_chains.py says why) ----
+#include "rr_chain.inc"
+constexpr int RR_CHUNK = 14;
 
-// acc += m * p[J] (skipped at compile time for a zero limb of the modulus)
-template <class P, int J>
-AMDMSM_DEV void rr_mad_p(int64_t& acc, int32_t m) {
-    constexpr uint32_t pl = rr_p_limb_c<P, J>::value;
-    if constexpr (pl != 0) rr_mad_vs(acc, m, (int32_t)pl);
-}
+AMDMSM_DEV void rr_mad_vv(int64_t& acc, int32_t a, int32_t b) { rr_chain<1>::vv(acc, a, b); }
+
 // acc += sum_{i in [I0, I0 + CNT)} a[i] * b[K - i]   /   m[i] * p[K - i]
 template <int K, int I0, size_t... J>
-AMDMSM_DEV void rr_col_vv(int64_t& acc, const int32_t* a, const int32_t* b, std::index_sequence<J...>) {
-    (rr_mad_vv(acc, a[I0 + (int)J], b[K - I0 - (int)J]), ...);
+AMDMSM_DEV void rr_chunk_vv(int64_t& acc, const int32_t* a, const int32_t* b, std::index_sequence<J...>) {
+    rr_chain<(int)sizeof...(J)>::vv(acc, a[I0 + (int)J]..., b[K - I0 - (int)J]...);
 }
 template <class P, int K, int I0, size_t... J>
-AMDMSM_DEV void rr_col_mp(int64_t& acc, const int32_t* m, std::index_sequence<J...>) {
-    (rr_mad_p<P, K - I0 - (int)J>(acc, m[I0 + (int)J]), ...);
+AMDMSM_DEV void rr_chunk_mp(int64_t& acc, const int32_t* m, std::index_sequence<J...>) {
+    rr_chain<(int)sizeof...(J)>::vs(acc, m[I0 + (int)J]..., (int32_t)rr_p_limb_c<P, K - I0 - (int)J>::value...);
+}
+template <int K, int I0, int CNT>
+AMDMSM_DEV void rr_col_vv(int64_t& acc, const int32_t* a, const int32_t* b) {
+    if constexpr (CNT > 0) {
+        constexpr int C = CNT < RR_CHUNK ? CNT : RR_CHUNK;
+        rr_chunk_vv<K, I0>(acc, a, b, std::make_index_sequence<C>{});
+        rr_col_vv<K, I0 + C, CNT - C>(acc, a, b);
+    }
+}
+template <class P, int K, int I0, int CNT>
+AMDMSM_DEV void rr_col_mp(int64_t& acc, const int32_t* m) {
+    if constexpr (CNT > 0) {
+        constexpr int C = CNT < RR_CHUNK ? CNT : RR_CHUNK;
+        rr_chunk_mp<P, K, I0>(acc, m, std::make_index_sequence<C>{});
+        rr_col_mp<P, K, I0 + C, CNT - C>(acc, m);
+    }
 }
 
 // r = (sum_j a_j * b_j) / rho mod p: product scanning, column k gathers a[i] b[k-i] and m[i] p[k-i];
@@ -153,14 +160,14 @@ AMDMSM_DEV void rr_dot_column(int64_t& acc, int32_t* m, int32_t* t, const int32_
     constexpr uint32_t NINV = P::INV & M;   // -p^-1 mod 2^B
     if constexpr (K < L) {
 #pragma unroll
-        for (int j = 0; j < T; ++j) rr_col_vv<K, 0>(acc, a[j], b[j], std::make_index_sequence<K + 1>{});
-        rr_col_mp<P, K, 0>(acc, m, std::make_index_sequence<K>{});
+        for (int j = 0; j < T; ++j) rr_col_vv<K, 0, K + 1>(acc, a[j], b[j]);
+        rr_col_mp<P, K, 0, K>(acc, m);
         m[K] = (int32_t)(((uint32_t)acc * NINV) & M);
-        rr_mad_p<P, 0>(acc, m[K]);
+        rr_col_mp<P, K, K, 1>(acc, m);
     } else {
 #pragma unroll
-        for (int j = 0; j < T; ++j) rr_col_vv<K, K - L + 1>(acc, a[j], b[j], std::make_index_sequence<2 * L - 1 - K>{});
-        rr_col_mp<P, K, K - L + 1>(acc, m, std::make_index_sequence<2 * L - 1 - K>{});
+        for (int j = 0; j < T; ++j) rr_col_vv<K, K - L + 1, 2 * L - 1 - K>(acc, a[j], b[j]);
+        rr_col_mp<P, K, K - L + 1, 2 * L - 1 - K>(acc, m);
         t[K - L] = (int32_t)((uint32_t)acc & M);
     }
     acc >>= B;
@@ -202,14 +209,14 @@ AMDMSM_DEV void rr_sqr_column(int64_t& acc, int32_t* m, int32_t* t, const int32_
     constexpr uint32_t NINV = P::INV & M;
     constexpr int I0 = K < L ? 0 : K - L + 1;
     constexpr int CNT = K == 0 ? 0 : ((K - 1) / 2 - I0 + 1);
-    rr_col_vv<K, I0>(acc, a, a2, std::make_index_sequence<(CNT > 0 ? CNT : 0)>{});
+    rr_col_vv<K, I0, (CNT > 0 ? CNT : 0)>(acc, a, a2);
     if constexpr (K % 2 == 0) rr_mad_vv(acc, a[K / 2], a[K / 2]);
     if constexpr (K < L) {
-        rr_col_mp<P, K, 0>(acc, m, std::make_index_sequence<K>{});
+        rr_col_mp<P, K, 0, K>(acc, m);
         m[K] = (int32_t)(((uint32_t)acc * NINV) & M);
-        rr_mad_p<P, 0>(acc, m[K]);
+        rr_col_mp<P, K, K, 1>(acc, m);
     } else {
-        rr_col_mp<P, K, K - L + 1>(acc, m, std::make_index_sequence<2 * L - 1 - K>{});
+        rr_col_mp<P, K, K - L + 1, 2 * L - 1 - K>(acc, m);
         t[K - L] = (int32_t)((uint32_t)acc & M);
     }
     acc >>= B;
@@ -461,41 +468,56 @@ AMDMSM_DEV bool xyzz_rr_same_x(XyzzRr<P>& acc, bool& inf, const Rr<P>& pp, const
 
 // acc += (wx, wy) (affine, canonical Montgomery words of fp.cuh; (0, 0) = infinity; neg: subtract).
 // madd-2008-s with the special-case ladder of G::mixed_add, as xyzz_madd (ec.cuh).
-template <class P>
-AMDMSM_DEV void xyzz_madd_rr(XyzzRr<P>& acc, bool& inf, const uint32_t (&wx)[P::N], const uint32_t (&wy)[P::N], bool neg) {
+// mid() runs once, in uniform control flow, after the last use of wx / wy: the caller's hook to overwrite them
+// with the NEXT point (its loads then travel under the eight products that follow; the words cost no extra
+// registers, the limbs of this point are dead by then).
+template <class P, class Mid>
+AMDMSM_DEV void xyzz_madd_rr(XyzzRr<P>& acc, bool& inf, const uint32_t (&wx)[P::N], const uint32_t (&wy)[P::N], bool neg, Mid&& mid) {
     constexpr int L = rr_shape<P>::L;
     uint32_t any = 0;
 #pragma unroll
     for (int i = 0; i < P::N; ++i) any |= wx[i] | wy[i];
-    if (any == 0) return;
-    if (inf) {
-        xyzz_rr_first(acc, wx, wy, neg);
-        inf = false;
-        return;
+    bool go = false;   // the general addition continues behind mid()
+    Rr<P> pp, r;
+    if (any != 0) {
+        if (inf) {
+            xyzz_rr_first(acc, wx, wy, neg);
+            inf = false;
+        } else {
+            Rr<P> px, py;
+            rr_from_words<P, 0>(px, wx);
+            rr_from_words<P, 0>(py, wy);
+            rr_cneg(py, py, neg);
+            rr_mul(pp, px, acc.zz);     // U2
+            rr_mul(r, py, acc.zzz);     // S2
+            rr_sub(pp, pp, acc.x);      // P = U2 - X1
+            rr_sub(r, r, acc.y);        // R = S2 - Y1
+            go = true;
+            if (__builtin_expect(rr_maybe_zero<P, rr_filter_k<P>()>(pp), 0)) {
+                if (xyzz_rr_same_x(acc, inf, pp, r, wx, wy, neg)) go = false;
+            }
+        }
     }
-    Rr<P> px, py, pp, r, ppp, q, t;
-    rr_from_words<P, 0>(px, wx);
-    rr_from_words<P, 0>(py, wy);
-    rr_cneg(py, py, neg);
-    rr_mul(pp, px, acc.zz);     // U2
-    rr_mul(r, py, acc.zzz);     // S2
-    rr_sub(pp, pp, acc.x);      // P = U2 - X1
-    rr_sub(r, r, acc.y);        // R = S2 - Y1
-    if (__builtin_expect(rr_maybe_zero<P, rr_filter_k<P>()>(pp), 0)) {
-        if (xyzz_rr_same_x(acc, inf, pp, r, wx, wy, neg)) return;
-    }
-    rr_sqr(ppp, pp);                    // PP
-    rr_mul(q, acc.x, ppp);              // Q = X1 PP
-    rr_mul(acc.zz, acc.zz, ppp);        // ZZ3 = ZZ1 PP
-    rr_mul(ppp, pp, ppp);               // PPP = P PP
-    rr_mul(acc.zzz, acc.zzz, ppp);      // ZZZ3 = ZZZ1 PPP
-    rr_sqr(t, r);                       // R^2
+    mid();
+    if (go) {
+        Rr<P> ppp, q, t;
+        rr_sqr(ppp, pp);                    // PP
+        rr_mul(q, acc.x, ppp);              // Q = X1 PP
+        rr_mul(acc.zz, acc.zz, ppp);        // ZZ3 = ZZ1 PP
+        rr_mul(ppp, pp, ppp);               // PPP = P PP
+        rr_mul(acc.zzz, acc.zzz, ppp);      // ZZZ3 = ZZZ1 PPP
+        rr_sqr(t, r);                       // R^2
 #pragma unroll
-    for (int i = 0; i < L; ++i) t.v[i] = t.v[i] - ppp.v[i] - 2 * q.v[i];   // X3 = R^2 - PPP - 2Q
-    rr_norm(acc.x, t);
-    rr_sub(q, q, acc.x);                // Q - X3
-    rr_neg(t, acc.y);
-    rr_mul2(acc.y, r, q, t, ppp);       // Y3 = R (Q - X3) - Y1 PPP
+        for (int i = 0; i < L; ++i) t.v[i] = t.v[i] - ppp.v[i] - 2 * q.v[i];   // X3 = R^2 - PPP - 2Q
+        rr_norm(acc.x, t);
+        rr_sub(q, q, acc.x);                // Q - X3
+        rr_neg(t, acc.y);
+        rr_mul2(acc.y, r, q, t, ppp);       // Y3 = R (Q - X3) - Y1 PPP
+    }
+}
+template <class P>
+AMDMSM_DEV void xyzz_madd_rr(XyzzRr<P>& acc, bool& inf, const uint32_t (&wx)[P::N], const uint32_t (&wy)[P::N], bool neg) {
+    xyzz_madd_rr<P>(acc, inf, wx, wy, neg, [] {});
 }
 
 // accumulator -> canonical (X, Y, ZZ, ZZZ) words of fp.cuh (factor 2^(32N)); all limbs zero (infinity) stay zero.
