@@ -41,16 +41,30 @@ CURVES = {"alt_bn128": 0, "bls12_377": 1, "bw6_761": 2, "bls12_381": 3}
 # one scalar + one affine base per scalar-mul
 ALGO_BYTES = {(0, 1): 96, (1, 1): 128, (1, 2): 224, (2, 1): 240, (0, 2): 160, (2, 2): 240, (3, 1): 128, (3, 2): 224}
 HBM_PEAK_GBS = 8000.0
-# What bounds k_accumulate is the issue rate of its multiply-accumulate pairs (v_mad_u64_u32 +
-# v_addc_co_u32, both half rate): 33.15 T lane-instructions/s measured with 4 waves per SIMD
-# (profiles/r01_ubench_instruction_rates.txt).  One Fq product = 2 N^2 pairs on N 32-bit limbs; one
-# mixed addition = 10 coordinate products (8M + 2S), a coordinate product in Fq2 = 3 (M) or 2 (S)
-# Fq products.
+# What bounds k_accumulate is the issue rate of its integer multiply-accumulates (tools/ubench.hip,
+# profiles/r03_ubench_instruction_rates.txt, 4 waves per SIMD):
+#   * prime-field groups (rr.cuh, reduced radix): one v_mad_i64_i32 per limb product, 30.27 T lane-instructions/s.
+#     A mixed addition is 7 products of 2 L^2, 2 squarings of L (L + 1) / 2 + L^2 and one fused sum of two products
+#     with one reduction (3 L^2) on L limbs of 28 / 29 bits.
+#   * Fq2 groups (fp.cuh / fp2h.cuh, 32-bit words): v_mad_u64_u32 + v_addc_co_u32 pairs, 33.15 T lane-instructions/s;
+#     one Fq product = 2 N^2 pairs, the Fq2 figure below is the unfused upper bound.
 MAC_PAIR_PEAK = 33.15e12
+MAD_I64_PEAK = 30.27e12
 FQ_LIMBS = {0: 8, 1: 12, 2: 24, 3: 12}
-# (G1, as k_accumulate computes it: 10 multiplications but 9 Montgomery reductions -- Y3 is one fused sum of two
-# products -- of N^2 multiply-accumulate pairs each = 9.5 products; the Fq2 figure is the unfused upper bound)
+RR_LIMBS = {0: 9, 1: 14, 2: 28, 3: 14}   # rr_shape<Fq>::L
 FQ_PRODUCTS_PER_MADD = {1: 9.5, 2: 27}   # Fq2: 8 M x 6 N^2 + 2 S x 4 N^2 - 2 N^2 (fused Y3) = 54 N^2 pairs
+
+
+def rr_group(curve, group):
+    """groups whose k_accumulate runs on reduced-radix limbs (libff_amd/build.py AMDMSM_ACC_RR): base field Fq"""
+    return group == 1 or curve == 2
+
+
+def rr_mads_per_madd(curve):
+    L = RR_LIMBS[curve]
+    return 7 * 2 * L * L + 2 * (L * (L + 1) // 2 + L * L) + 3 * L * L
+
+
 FR_MODULUS = {
     0: 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001,
     1: 0x12AB655E9A2CA55660B44D1E5C37B00159AA76FED00000010A11800000000001,
@@ -298,10 +312,23 @@ def timed_msm(tm, eng, msm, bases, scalars, n, steps, warmup, window_bits=0, wan
 def roofline_of(curve_name, curve, group, n_launch, plan, acc_ms, log2n_for_pmc):
     algo_bytes = ALGO_BYTES[(curve, group)] * n_launch
     achieved = algo_bytes / (acc_ms * 1e-3) / 1e9
-    fq_products = FQ_PRODUCTS_PER_MADD[group if not (curve == 2) else 1]
     # list entries: one per (digit column, window); the endomorphism split has two half-length columns per point
     columns = 2 if plan.get("endomorphism") else 1
-    lane_instr = float(n_launch) * columns * plan["num_windows"] * fq_products * 4 * FQ_LIMBS[curve] ** 2
+    entries = float(n_launch) * columns * plan["num_windows"]
+    if rr_group(curve, group):
+        lane_instr = entries * rr_mads_per_madd(curve)
+        mac_peak = MAD_I64_PEAK
+        mac_what = ("v_mad_i64_i32 issues of the reduced-radix Montgomery products in k_accumulate (every list entry counted as "
+                    f"a full mixed addition: {rr_mads_per_madd(curve)} multiply-accumulates on {RR_LIMBS[curve]} limbs) against the "
+                    "instruction's measured issue rate at 4 waves/SIMD; the other fifth of the loop's issue time is its "
+                    "shifts, masks and limb-wise additions")
+    else:
+        fq_products = FQ_PRODUCTS_PER_MADD[group]
+        lane_instr = entries * fq_products * 4 * FQ_LIMBS[curve] ** 2
+        mac_peak = MAC_PAIR_PEAK
+        mac_what = ("v_mad_u64_u32 + v_addc_co_u32 issues of the Montgomery products in k_accumulate (every list entry counted "
+                    "as a full mixed addition: 54 N^2 pairs in Fq2, the unfused bound) against the pair's measured issue rate "
+                    "at 4 waves/SIMD")
     mac_rate = lane_instr / (acc_ms * 1e-3)
     traffic, traffic_src = pmc_traffic(curve_name, group, log2n_for_pmc, plan["c"]) if log2n_for_pmc else (None, None)
     return {
@@ -318,11 +345,8 @@ def roofline_of(curve_name, curve, group, n_launch, plan, acc_ms, log2n_for_pmc)
         "algorithmic_bytes_per_launch": algo_bytes,
         "kernel_ms": acc_ms,
         "note": "integer-ALU bound path (no MFMA); HBM fraction is small by construction",
-        "mac_issue": {"achieved": mac_rate / 1e12, "peak": MAC_PAIR_PEAK / 1e12, "unit": "T lane-instr/s",
-                      "frac": mac_rate / MAC_PAIR_PEAK,
-                      "what": "v_mad_u64_u32 + v_addc_co_u32 issues of the Montgomery products in k_accumulate "
-                              "(every list entry counted as a full mixed addition: 19 N^2 pairs in Fq) against the pair's "
-                              "measured issue rate at 4 waves/SIMD"},
+        "mac_issue": {"achieved": mac_rate / 1e12, "peak": mac_peak / 1e12, "unit": "T lane-instr/s",
+                      "frac": mac_rate / mac_peak, "what": mac_what},
     }
 
 

@@ -98,8 +98,11 @@ def build(force=False, verbose=True, jobs=None):
         o = os.path.join(OBJ, f"group_{g}.o")
         objs.append(o)
         if force or _newer(o, DEVICE_DEPS):
+            # an experiment flag replaces the group's own setting of the same macro
+            names = {f.split("=")[0] for f in extra}
+            own = [f for f in GROUP_FLAGS.get(g, []) if f.split("=")[0] not in names]
             tasks.append([cc, *COMMON, "-c", os.path.join(CSRC, "msm_group.hip"),
-                          f"-DAMDMSM_GROUP={g}", f"-DAMDMSM_VT=vt_{g}", *GROUP_FLAGS.get(g, []), *extra, "-o", o])
+                          f"-DAMDMSM_GROUP={g}", f"-DAMDMSM_VT=vt_{g}", *own, *extra, "-o", o])
     # AMDMSM_FFI_NO_REFERENCE_SYMBOLS=1: leave out the reference's own FFI names (<curve>_init / _g1_add /
     # _g1_mul, include/libff_amd_ffi.h) so that the library can sit next to libff-ffi
     no_ref = os.environ.get("AMDMSM_FFI_NO_REFERENCE_SYMBOLS", "0") not in ("", "0")

@@ -180,6 +180,7 @@ int main(int argc, char** argv) {
 #if PROTO_FIELD == 1
     bad += run<alt_bn128_fq, 4, 4>("alt_bn128 Fq");
     bad += run<alt_bn128_fq, 4, 3>("alt_bn128 Fq");
+    bad += run<alt_bn128_fq, 4, 2>("alt_bn128 Fq");
 #elif PROTO_FIELD == 2
     bad += run<bls12_377_fq, 3, 3>("bls12_377 Fq");
     bad += run<bls12_377_fq, 3, 2>("bls12_377 Fq");

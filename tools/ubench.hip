@@ -62,6 +62,14 @@ __global__ void __launch_bounds__(256) probe(uint32_t* out, uint32_t seed) {
                 asm volatile("v_mul_f64 %0, %0, %1" : "+v"(da[k]) : "v"(db[k]));
             } else if (KIND == 12) {  // v_add_f64
                 asm volatile("v_add_f64 %0, %0, %1" : "+v"(da[k]) : "v"(db[k]));
+            } else if (KIND == 13) {  // v_mad_i64_i32, UNROLL independent accumulators (carry-out to an SGPR pair, unused)
+                asm volatile("v_mad_i64_i32 %0, s[20:21], %1, %2, %0" : "+v"(acc[k]) : "v"(a[k]), "v"(b[k]) : "s20", "s21");
+            } else if (KIND == 14) {  // v_mad_i64_i32, ONE accumulator: the dependent chain of a product-scan column (rr.cuh)
+                asm volatile("v_mad_i64_i32 %0, s[20:21], %1, %2, %0" : "+v"(acc[0]) : "v"(a[k]), "v"(b[k]) : "s20", "s21");
+            } else if (KIND == 15) {  // v_ashrrev_i64
+                asm volatile("v_ashrrev_i64 %0, 1, %0" : "+v"(acc[k]));
+            } else if (KIND == 16) {  // v_and_b32 (plain 32-bit logic)
+                asm volatile("v_and_b32 %0, %0, %1" : "+v"(a[k]) : "v"(b[k]));
             }
         }
     }
@@ -101,7 +109,7 @@ int run(const char* name, int instr_per_step, uint32_t* d_out, int waves_per_sim
 int main() {
     uint32_t* d_out;
     CHECK(hipMalloc(&d_out, 256 * 256 * 16 * sizeof(uint32_t)));
-    for (int w : {1, 2, 4, 8}) {
+    for (int w : {1, 2, 3, 4, 8}) {
         run<7>("v_add_u32", 1, d_out, w);
         run<0>("v_mad_u64_u32", 1, d_out, w);
         run<8>("v_mad_u64_u32 + v_addc_co_u32", 2, d_out, w);
@@ -115,6 +123,10 @@ int main() {
         run<4>("v_fma_f64", 1, d_out, w);
         run<11>("v_mul_f64", 1, d_out, w);
         run<12>("v_add_f64", 1, d_out, w);
+        run<13>("v_mad_i64_i32", 1, d_out, w);
+        run<14>("v_mad_i64_i32, one accumulator", 1, d_out, w);
+        run<15>("v_ashrrev_i64", 1, d_out, w);
+        run<16>("v_and_b32", 1, d_out, w);
         printf("\n");
     }
     CHECK(hipFree(d_out));
