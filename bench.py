@@ -46,23 +46,22 @@ HBM_PEAK_GBS = 8000.0
 #   * prime-field groups (rr.cuh, reduced radix): one v_mad_i64_i32 per limb product, 30.27 T lane-instructions/s.
 #     A mixed addition is 7 products of 2 L^2, 2 squarings of L (L + 1) / 2 + L^2 and one fused sum of two products
 #     with one reduction (3 L^2) on L limbs of 28 / 29 bits.
-#   * Fq2 groups (fp.cuh / fp2h.cuh, 32-bit words): v_mad_u64_u32 + v_addc_co_u32 pairs, 33.15 T lane-instructions/s;
-#     one Fq product = 2 N^2 pairs, the Fq2 figure below is the unfused upper bound.
-MAC_PAIR_PEAK = 33.15e12
+#   * Fq2 groups: the same on lane pairs (rr.cuh Rr2H), see rr_mads_per_madd.
+#   (The 32-bit loop of rounds 1-2 paid a v_mad_u64_u32 + v_addc_co_u32 pair per limb product, 33.15 T lane-instr/s.)
 MAD_I64_PEAK = 30.27e12
 FQ_LIMBS = {0: 8, 1: 12, 2: 24, 3: 12}
 RR_LIMBS = {0: 9, 1: 14, 2: 28, 3: 14}   # rr_shape<Fq>::L
-FQ_PRODUCTS_PER_MADD = {1: 9.5, 2: 27}   # Fq2: 8 M x 6 N^2 + 2 S x 4 N^2 - 2 N^2 (fused Y3) = 54 N^2 pairs
 
 
-def rr_group(curve, group):
-    """groups whose k_accumulate runs on reduced-radix limbs (libff_amd/build.py AMDMSM_ACC_RR): base field Fq"""
-    return group == 1 or curve == 2
-
-
-def rr_mads_per_madd(curve):
+def rr_mads_per_madd(curve, group):
+    """v_mad_i64_i32 issues of one mixed addition in k_accumulate (rr.cuh), summed over the lanes that share it"""
     L = RR_LIMBS[curve]
-    return 7 * 2 * L * L + 2 * (L * (L + 1) // 2 + L * L) + 3 * L * L
+    if group == 1 or curve == 2:   # coordinates in Fq: 7 products, 2 squarings, one fused sum of two products
+        return 7 * 2 * L * L + 2 * (L * (L + 1) // 2 + L * L) + 3 * L * L
+    # Fq2 over a lane pair, per lane: a product is a fused sum of two Fq products (3 L^2), a complex squaring (u^2 = -1)
+    # one Fq product (2 L^2), Y3 one fused sum of four (5 L^2) where a column holds it, else two products
+    per_lane = {0: 6 * 3 + 2 * 2 + 2 * 3, 1: 8 * 3 + 2 * 3, 3: 6 * 3 + 2 * 2 + 5}[curve] * L * L
+    return 2 * per_lane
 
 
 FR_MODULUS = {
@@ -315,20 +314,12 @@ def roofline_of(curve_name, curve, group, n_launch, plan, acc_ms, log2n_for_pmc)
     # list entries: one per (digit column, window); the endomorphism split has two half-length columns per point
     columns = 2 if plan.get("endomorphism") else 1
     entries = float(n_launch) * columns * plan["num_windows"]
-    if rr_group(curve, group):
-        lane_instr = entries * rr_mads_per_madd(curve)
-        mac_peak = MAD_I64_PEAK
-        mac_what = ("v_mad_i64_i32 issues of the reduced-radix Montgomery products in k_accumulate (every list entry counted as "
-                    f"a full mixed addition: {rr_mads_per_madd(curve)} multiply-accumulates on {RR_LIMBS[curve]} limbs) against the "
-                    "instruction's measured issue rate at 4 waves/SIMD; the other fifth of the loop's issue time is its "
-                    "shifts, masks and limb-wise additions")
-    else:
-        fq_products = FQ_PRODUCTS_PER_MADD[group]
-        lane_instr = entries * fq_products * 4 * FQ_LIMBS[curve] ** 2
-        mac_peak = MAC_PAIR_PEAK
-        mac_what = ("v_mad_u64_u32 + v_addc_co_u32 issues of the Montgomery products in k_accumulate (every list entry counted "
-                    "as a full mixed addition: 54 N^2 pairs in Fq2, the unfused bound) against the pair's measured issue rate "
-                    "at 4 waves/SIMD")
+    lane_instr = entries * rr_mads_per_madd(curve, group)
+    mac_peak = MAD_I64_PEAK
+    mac_what = ("v_mad_i64_i32 issues of the reduced-radix Montgomery products in k_accumulate (every list entry counted as "
+                f"a full mixed addition: {rr_mads_per_madd(curve, group)} multiply-accumulates on limbs of {RR_LIMBS[curve]} x "
+                f"{29 if RR_LIMBS[curve] == 9 else 28} bits) against the instruction's measured issue rate at 4 waves/SIMD; the "
+                "rest of the loop's issue time is its shifts, masks and limb-wise additions")
     mac_rate = lane_instr / (acc_ms * 1e-3)
     traffic, traffic_src = pmc_traffic(curve_name, group, log2n_for_pmc, plan["c"]) if log2n_for_pmc else (None, None)
     return {

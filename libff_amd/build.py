@@ -53,7 +53,8 @@ for _g in ("bls12_377_g1", "bls12_381_g1"):
 # v_mad_i64_i32 per limb product and no carry instruction behind it, limb-wise linear operations): 1.3x the
 # mixed additions per second of the 32-bit loop on every field (tools/proto_rr.hip).  Register budget: three
 # waves per SIMD for the 9-limb field (134 registers), two for 14 and 28 limbs.
-for _g, _w in (("alt_bn128_g1", 3), ("bls12_377_g1", 2), ("bls12_381_g1", 2), ("bw6_761_g1", 2), ("bw6_761_g2", 2)):
+for _g, _w in (("alt_bn128_g1", 3), ("bls12_377_g1", 2), ("bls12_381_g1", 2), ("bw6_761_g1", 2), ("bw6_761_g2", 2),
+               ("alt_bn128_g2", 3), ("bls12_377_g2", 2), ("bls12_381_g2", 2)):
     GROUP_FLAGS[_g] = [f for f in GROUP_FLAGS[_g] if not f.startswith("-DAMDMSM_ACC_WAVES=")] + ["-DAMDMSM_ACC_RR=1", f"-DAMDMSM_ACC_WAVES={_w}"]
 ARCH = "gfx950"
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-I" + INCLUDE, "-I" + CSRC,

@@ -100,22 +100,27 @@ constexpr int ACC_LANES = split_sel<GP::DEG>::LANES;     // physical lanes per a
 using ER = typename std::conditional<(ACC_LANES == 2), EA, E>::type;
 constexpr int RED_LANES = ACC_LANES;
 constexpr uint32_t RED_FOLD = 64u / RED_LANES;
+#if AMDMSM_ACC_RR
+static_assert(GP::DEG == 1 || AMDMSM_ACC_SPLIT, "reduced-radix Fq2 accumulation works on lane pairs");
+template <int DEG> struct rr_el_sel { using type = Rr<FQ>; };
+template <> struct rr_el_sel<2> { using type = Rr2H<FQ, (GP::NR_SMALL == 0 ? -1 : GP::NR_SMALL)>; };
+using ERR = typename rr_el_sel<GP::DEG>::type;   // element type of the reduced-radix accumulation loop
+#endif
 
 constexpr int EW = FQ::N * GP::DEG;   // words per coordinate
 constexpr int AFFW = 2 * EW;          // words per compact affine point
 constexpr int XYZW = 3 * EW;          // words per (X, Y, Z) record
 constexpr int ZZW = 4 * EW;           // words per (X, Y, ZZ, ZZZ) bucket accumulator
-// AMDMSM_ACC_RR (prime-field groups): k_accumulate keeps its accumulators on reduced-radix limbs (rr.cuh) and
-// writes them as they are -- 4 L words per record; k_rr_export rewrites every record in place as canonical
-// (X, Y, ZZ, ZZZ) words before any other kernel reads it.  ZZS = words between two records of the bucket /
-// partial arrays (group_vtable::bucket_words).
+// AMDMSM_ACC_RR: k_accumulate keeps its accumulators on reduced-radix limbs (rr.cuh; an Fq2 element over a pair of
+// lanes as with AMDMSM_ACC_SPLIT) and writes them as they are -- 4 L limbs per component; k_rr_export rewrites every
+// record in place as canonical (X, Y, ZZ, ZZZ) words before any other kernel reads it.  ZZS = words between two
+// records of the bucket / partial arrays (group_vtable::bucket_words).
 #ifndef AMDMSM_ACC_RR
 #define AMDMSM_ACC_RR 0
 #endif
 #if AMDMSM_ACC_RR
-static_assert(GP::DEG == 1 && !AMDMSM_ACC_SPLIT, "reduced-radix accumulation is built for prime fields");
 constexpr int RRL = rr_shape<FQ>::L;
-constexpr int ZZS = 4 * RRL;
+constexpr int ZZS = 4 * RRL * GP::DEG;   // [component][X, Y, ZZ, ZZZ][limb]: a lane's 4 L limbs are contiguous
 #else
 constexpr int ZZS = ZZW;
 #endif
@@ -958,34 +963,34 @@ __global__ void __launch_bounds__(SORT_TPB) k_sort_big_scatter(const uint32_t* _
 // instruction behind a multiply, limb-wise linear operations, an infinity flag instead of a zero test).
 #if AMDMSM_ACC_RR
 struct acc_state {
-    XyzzRr<FQ> a;
+    XyzzRr<ERR> a;
     bool inf;
 };
 AMDMSM_DEV void acc_reset(acc_state& s) { s.inf = true; }   // the limbs are dead while inf is set
-// the record as it is: 4 L limbs (all zero: infinity); k_rr_export makes canonical words of it
+// the record as it is: this lane's 4 L limbs (all zero: infinity); k_rr_export makes canonical words of it
 AMDMSM_DEV void acc_store(uint32_t* q, const acc_state& s) {
     const int32_t keep = s.inf ? 0 : -1;
-    uint32_t w[ZZS];
+    uint32_t w[4 * RRL];
 #pragma unroll
     for (int i = 0; i < RRL; ++i) {
-        w[i] = (uint32_t)(s.a.x.v[i] & keep);
-        w[RRL + i] = (uint32_t)(s.a.y.v[i] & keep);
-        w[2 * RRL + i] = (uint32_t)(s.a.zz.v[i] & keep);
-        w[3 * RRL + i] = (uint32_t)(s.a.zzz.v[i] & keep);
+        w[i] = (uint32_t)(re_limb(s.a.x, i) & keep);
+        w[RRL + i] = (uint32_t)(re_limb(s.a.y, i) & keep);
+        w[2 * RRL + i] = (uint32_t)(re_limb(s.a.zz, i) & keep);
+        w[3 * RRL + i] = (uint32_t)(re_limb(s.a.zzz, i) & keep);
     }
-    uint4* q4 = reinterpret_cast<uint4*>(q);
+    uint4* q4 = reinterpret_cast<uint4*>(q + (GP::DEG == 2 && (threadIdx.x & 1u) ? 4 * RRL : 0));
 #pragma unroll
-    for (int i = 0; i < ZZS / 4; ++i) q4[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+    for (int i = 0; i < RRL; ++i) q4[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
 }
-// one affine record (x, y) as words
+// this lane's component of one affine record (x, y) as words
 struct aff_words {
     uint32_t x[FQ::N], y[FQ::N];
 };
 AMDMSM_DEV void aff_words_load(aff_words& p, const uint32_t* rec) {
-    const uint4* r4 = reinterpret_cast<const uint4*>(rec);
+    const uint4* r4 = reinterpret_cast<const uint4*>(rec + (GP::DEG == 2 && (threadIdx.x & 1u) ? FQ::N : 0));
 #pragma unroll
     for (int i = 0; i < FQ::N / 4; ++i) {
-        const uint4 a = r4[i], b = r4[FQ::N / 4 + i];
+        const uint4 a = r4[i], b = r4[EW / 4 + i];
         p.x[4 * i] = a.x; p.x[4 * i + 1] = a.y; p.x[4 * i + 2] = a.z; p.x[4 * i + 3] = a.w;
         p.y[4 * i] = b.x; p.y[4 * i + 1] = b.y; p.y[4 * i + 2] = b.z; p.y[4 * i + 3] = b.w;
     }
@@ -1151,7 +1156,7 @@ __global__ void __launch_bounds__(TPB, AMDMSM_ACC_WAVES) k_accumulate(const uint
             } while (bend == k);   // skip empty buckets (k < total = e[B-1] bounds the walk)
         }
         const bool neg = pneg;
-        xyzz_madd_rr<FQ>(acc.a, acc.inf, pw.x, pw.y, neg, [&] {
+        xyzz_madd_rr(acc.a, acc.inf, pw.x, pw.y, neg, [&] {
             if (k + 1 < hi) {
                 if (((k + 1 - lo) & 15u) == 0) stage(k + 1);
                 fetch(k + 1);
@@ -1216,38 +1221,47 @@ __global__ void __launch_bounds__(TPB, AMDMSM_ACC_WAVES) k_accumulate(const uint
 }
 
 #if AMDMSM_ACC_RR
-// Every record k_accumulate wrote (buckets, part_first, part_last: 4 L reduced-radix limbs each, ZZS words apart)
-// becomes canonical (X, Y, ZZ, ZZZ) words at the start of the same record.  Records nobody wrote hold zeros
-// (buckets: infinity) or leftovers (partials the fix-up does not look at): both pass through harmlessly.
+// Every record k_accumulate wrote (buckets, part_first, part_last: 4 L reduced-radix limbs per component, ZZS words
+// apart) becomes canonical (X, Y, ZZ, ZZZ) words at the start of the same record.  One thread per (record, component);
+// the two threads of an Fq2 record are neighbours in a wave: both have read their limbs before either writes.
+// Records nobody wrote hold zeros (buckets: infinity) or leftovers (partials the fix-up does not look at): both pass
+// through harmlessly.
 __global__ void __launch_bounds__(TPB) k_rr_export(uint32_t* __restrict__ buckets, size_t n_buckets, uint32_t* __restrict__ part_first,
                                                    uint32_t* __restrict__ part_last, size_t n_lanes) {
-    const size_t i = gtid();
-    if (i >= n_buckets + 2 * n_lanes) return;
-    uint32_t* q = i < n_buckets ? buckets + i * ZZS
-                                : (i < n_buckets + n_lanes ? part_first + (i - n_buckets) * ZZS : part_last + (i - n_buckets - n_lanes) * ZZS);
-    uint32_t w[ZZS];
-    const uint4* q4 = reinterpret_cast<const uint4*>(q);
+    const size_t t = gtid();
+    const size_t i = t / GP::DEG;
+    const uint32_t comp = (uint32_t)(t % GP::DEG);
+    const bool live = i < n_buckets + 2 * n_lanes;
+    uint32_t* q = !live ? buckets
+                        : (i < n_buckets ? buckets + i * ZZS
+                                         : (i < n_buckets + n_lanes ? part_first + (i - n_buckets) * ZZS : part_last + (i - n_buckets - n_lanes) * ZZS));
+    uint32_t w[4 * RRL];
+    const uint4* q4 = reinterpret_cast<const uint4*>(q + comp * 4 * RRL);
     uint32_t any = 0;
 #pragma unroll
-    for (int k = 0; k < ZZS / 4; ++k) {
-        const uint4 v = q4[k];
+    for (int k = 0; k < RRL; ++k) {
+        const uint4 v = live ? q4[k] : make_uint4(0, 0, 0, 0);
         w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
         any |= v.x | v.y | v.z | v.w;
     }
-    if (any == 0) return;
-    XyzzRr<FQ> a;
+    // an Fq2 record is infinity when BOTH components are all zero; a zero component of a finite point must still be
+    // written (its words move)
+    bool rec_zero = any == 0;
+    if (GP::DEG == 2) rec_zero = rec_zero && (rr_pair_swap(any == 0 ? 1 : 0) != 0);
+    if (!live || rec_zero) return;
+    constexpr int D = rr_shape<FQ>::D;
+    Rr<FQ> a;
+    uint32_t out[FQ::N];
 #pragma unroll
-    for (int k = 0; k < RRL; ++k) {
-        a.x.v[k] = (int32_t)w[k];
-        a.y.v[k] = (int32_t)w[RRL + k];
-        a.zz.v[k] = (int32_t)w[2 * RRL + k];
-        a.zzz.v[k] = (int32_t)w[3 * RRL + k];
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int k = 0; k < RRL; ++k) a.v[k] = (int32_t)w[j * RRL + k];
+        if (j < 2) rr_export_component<FQ, 0>(out, a);
+        else rr_export_component<FQ, D>(out, a);
+        uint4* o4 = reinterpret_cast<uint4*>(q + (j * GP::DEG + comp) * FQ::N);
+#pragma unroll
+        for (int k = 0; k < FQ::N / 4; ++k) o4[k] = make_uint4(out[4 * k], out[4 * k + 1], out[4 * k + 2], out[4 * k + 3]);
     }
-    uint32_t out[ZZW];
-    xyzz_rr_export<FQ>(out, a);
-    uint4* o4 = reinterpret_cast<uint4*>(q);
-#pragma unroll
-    for (int k = 0; k < ZZW / 4; ++k) o4[k] = make_uint4(out[4 * k], out[4 * k + 1], out[4 * k + 2], out[4 * k + 3]);
 }
 #endif
 
@@ -2610,8 +2624,8 @@ void l_accumulate(hipStream_t st, const uint32_t* ends, const uint32_t* lists, s
                        endo_pts ? (uint32_t)n_real : 0x80000000u, sync_waves);
 #endif
 #if AMDMSM_ACC_RR
-    hipLaunchKernelGGL(k_rr_export, dim3(blocks_for((size_t)W * B + 2 * (size_t)W * T)), dim3(TPB), 0, st, buckets, (size_t)W * B,
-                       part_first, part_last, (size_t)W * T);
+    hipLaunchKernelGGL(k_rr_export, dim3(blocks_for(((size_t)W * B + 2 * (size_t)W * T) * GP::DEG)), dim3(TPB), 0, st, buckets,
+                       (size_t)W * B, part_first, part_last, (size_t)W * T);
 #endif
 }
 void l_endo_points(hipStream_t st, const uint32_t* bases, size_t n, uint32_t* out) {

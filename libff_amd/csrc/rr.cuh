@@ -147,6 +147,8 @@ AMDMSM_DEV void rr_col_mp(int64_t& acc, const int32_t* m) {
     }
 }
 
+// Invariant of every caller: the limbs of a factor stay within 2^B + 8 in magnitude (a carry step, rr_norm, follows
+// whatever could exceed that) unless the callee states a weight (rr_fits).
 // r = (sum_j a_j * b_j) / rho mod p: product scanning, column k gathers a[i] b[k-i] and m[i] p[k-i];
 // m[k] makes the column's low B bits vanish.  Exactly (sum a_j b_j + m p) / rho as integers with
 // 0 <= m < rho, so the result lies in (S / rho, S / rho + p).  Output limbs 0..L-2 in [0, 2^B),
@@ -385,31 +387,194 @@ AMDMSM_DEV void rr_to_words(uint32_t (&w)[P::N], const Rr<P>& a) {
     }
 }
 
-// ---- XYZZ accumulator in reduced radix ----------------------------------------------------------
-// x, y carry the Montgomery factor rho; zz, zzz carry rho * 2^D, so that a product with an affine
-// coordinate straight from memory (factor 2^(32N), fp.cuh form) lands on the factor rho:
-// (x2 2^(32N)) (zz rho 2^D) / rho = x2 zz rho.  Every other product of madd-2008-s keeps its
-// operands' factors (rho * rho / rho, rho 2^D * rho / rho).
-template <class P>
-struct XyzzRr {
-    Rr<P> x, y, zz, zzz;
-};
-
 template <class P, class C>
 AMDMSM_DEV void rr_set_const(Rr<P>& r) {
 #pragma unroll
     for (int i = 0; i < Rr<P>::L; ++i) r.v[i] = (int32_t)C::value.v[i];
 }
 
-// the first point of a bucket: (x 2^D, y 2^D, 1, 1) in the factors above (values below 2^D p)
+// ---- elements: Fq, or Fq2 split over a pair of lanes ---------------------------------------------
+// The mixed addition below is written once over an element type E with the operations re_*:
+//   Rr<P>        one Fq element per lane (G1 groups, bw6_761 G2)
+//   Rr2H<P, NR>  one Fq2 = Fq[u] / (u^2 - NR) element per PAIR of lanes, the even lane holding c0 and the odd
+//                lane c1 (the layout of fp2h.cuh, whose 32-bit form this replaces in k_accumulate): an Fq2
+//                product is one fused sum of two Fq products per lane,
+//                    c0 = x0 y0 + (NR x1) y1        c1 = x0 y1 + x1 y0,
+//                the partner's operands fetched with DPP quad_perm moves.  Signed limbs make the negative
+//                terms plain operands (-c, NR x with NR < 0): no offset by a multiple of p as in fp_neg_raw.
+//                Both lanes of a pair run the same control flow (predicates are made pair-uniform).
+template <class P, int NR>
+struct Rr2H {
+    using params = P;
+    Rr<P> h;
+};
+template <class E> struct re_info;
+template <class P> struct re_info<Rr<P>> {
+    using params = P;
+    static constexpr bool PAIR = false;
+};
+template <class P, int NR> struct re_info<Rr2H<P, NR>> {
+    using params = P;
+    static constexpr bool PAIR = true;
+};
+
+AMDMSM_DEV bool rr_pair_odd() { return (threadIdx.x & 1u) != 0; }
+AMDMSM_DEV int32_t rr_pair_swap(int32_t v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false); }   // quad_perm [1, 0, 3, 2]
 template <class P>
-AMDMSM_DEV void xyzz_rr_first(XyzzRr<P>& acc, const uint32_t (&wx)[P::N], const uint32_t (&wy)[P::N], bool neg) {
+AMDMSM_DEV void rr_pair_swap(Rr<P>& r, const Rr<P>& a) {
+#pragma unroll
+    for (int i = 0; i < Rr<P>::L; ++i) r.v[i] = rr_pair_swap(a.v[i]);
+}
+template <class P>
+AMDMSM_DEV void rr_pair_select(Rr<P>& r, bool odd, const Rr<P>& if_odd, const Rr<P>& if_even) {
+#pragma unroll
+    for (int i = 0; i < Rr<P>::L; ++i) r.v[i] = odd ? if_odd.v[i] : if_even.v[i];
+}
+// true in both lanes of a pair iff true in both
+template <class E>
+AMDMSM_DEV bool re_all(bool mine) {
+    if constexpr (re_info<E>::PAIR) return mine && (rr_pair_swap(mine ? 1 : 0) != 0);
+    else return mine;
+}
+
+// component-wise operations
+template <class P> AMDMSM_DEV void re_sub(Rr<P>& r, const Rr<P>& a, const Rr<P>& b) { rr_sub(r, a, b); }
+template <class P> AMDMSM_DEV void re_neg(Rr<P>& r, const Rr<P>& a) { rr_neg(r, a); }
+template <class P> AMDMSM_DEV void re_cneg(Rr<P>& r, const Rr<P>& a, bool n) { rr_cneg(r, a, n); }
+template <class P> AMDMSM_DEV void re_norm(Rr<P>& r, const Rr<P>& a) { rr_norm(r, a); }
+template <class P> AMDMSM_DEV void re_zero(Rr<P>& r) { rr_zero(r); }
+template <class P, int NR> AMDMSM_DEV void re_sub(Rr2H<P, NR>& r, const Rr2H<P, NR>& a, const Rr2H<P, NR>& b) { rr_sub(r.h, a.h, b.h); }
+template <class P, int NR> AMDMSM_DEV void re_neg(Rr2H<P, NR>& r, const Rr2H<P, NR>& a) { rr_neg(r.h, a.h); }
+template <class P, int NR> AMDMSM_DEV void re_cneg(Rr2H<P, NR>& r, const Rr2H<P, NR>& a, bool n) { rr_cneg(r.h, a.h, n); }
+template <class P, int NR> AMDMSM_DEV void re_norm(Rr2H<P, NR>& r, const Rr2H<P, NR>& a) { rr_norm(r.h, a.h); }
+template <class P, int NR> AMDMSM_DEV void re_zero(Rr2H<P, NR>& r) { rr_zero(r.h); }
+template <class P> AMDMSM_DEV int32_t& re_limb(Rr<P>& a, int i) { return a.v[i]; }
+template <class P, int NR> AMDMSM_DEV int32_t& re_limb(Rr2H<P, NR>& a, int i) { return a.h.v[i]; }
+template <class P> AMDMSM_DEV const int32_t& re_limb(const Rr<P>& a, int i) { return a.v[i]; }
+template <class P, int NR> AMDMSM_DEV const int32_t& re_limb(const Rr2H<P, NR>& a, int i) { return a.h.v[i]; }
+// limbs of (this lane's component words << OFF)
+template <int OFF, class P> AMDMSM_DEV void re_from_words(Rr<P>& r, const uint32_t (&w)[P::N]) { rr_from_words<P, OFF>(r, w); }
+template <int OFF, class P, int NR> AMDMSM_DEV void re_from_words(Rr2H<P, NR>& r, const uint32_t (&w)[P::N]) { rr_from_words<P, OFF>(r.h, w); }
+// the element (c, 0), c = 2^E mod p
+template <int E, class P> AMDMSM_DEV void re_set_pow2(Rr<P>& r) { rr_set_const<P, rr_pow2<P, E>>(r); }
+template <int E, class P, int NR> AMDMSM_DEV void re_set_pow2(Rr2H<P, NR>& r) {
+    const int32_t keep = rr_pair_odd() ? 0 : -1;
+#pragma unroll
+    for (int i = 0; i < Rr<P>::L; ++i) r.h.v[i] = (int32_t)rr_pow2<P, E>::value.v[i] & keep;
+}
+// residue tests (pair-uniform)
+template <int K, class P> AMDMSM_DEV bool re_maybe_zero(const Rr<P>& a) { return rr_maybe_zero<P, K>(a); }
+template <int K, class P, int NR> AMDMSM_DEV bool re_maybe_zero(const Rr2H<P, NR>& a) { return re_all<Rr2H<P, NR>>(rr_maybe_zero<P, K>(a.h)); }
+template <class P> AMDMSM_DEV bool re_is_zero_exact(const Rr<P>& a) { return rr_is_zero_exact(a); }
+template <class P, int NR> AMDMSM_DEV bool re_is_zero_exact(const Rr2H<P, NR>& a) { return re_all<Rr2H<P, NR>>(rr_is_zero_exact(a.h)); }
+
+// products
+template <class P> AMDMSM_DEV void re_mul(Rr<P>& r, const Rr<P>& a, const Rr<P>& b) { rr_mul(r, a, b); }
+template <class P> AMDMSM_DEV void re_sqr(Rr<P>& r, const Rr<P>& a) { rr_sqr(r, a); }
+// r = a b - c d, limbs of the result within one carry step of B bits
+template <class P> AMDMSM_DEV void re_mul_sub_mul(Rr<P>& r, const Rr<P>& a, const Rr<P>& b, const Rr<P>& c, const Rr<P>& d) {
+    Rr<P> nc;
+    rr_neg(nc, c);
+    rr_mul2(r, a, b, nc, d);
+}
+// NR * a on limbs (|NR| small: the factor of a product may carry limbs of B + 3 bits, rr_fits)
+template <class P, int NR>
+AMDMSM_DEV void rr_nr_times(Rr<P>& r, const Rr<P>& a) {
+#pragma unroll
+    for (int i = 0; i < Rr<P>::L; ++i) r.v[i] = NR * a.v[i];
+}
+// does a column of T products with factor limbs of (2^B + 8) * F1 and (2^B + 8), plus the m p products, stay below 2^63?
+template <class P>
+constexpr bool rr_fits(double weighted_products) {
+    const double l = (double)rr_shape<P>::L, b = (double)(1u << rr_shape<P>::B) + 8.0;
+    return (weighted_products + 1.0) * l * b * b < 9.2e18;
+}
+template <class P, int NR>
+AMDMSM_DEV void re_mul(Rr2H<P, NR>& r, const Rr2H<P, NR>& x, const Rr2H<P, NR>& y) {
+    static_assert(rr_fits<P>(1.0 + (NR < 0 ? -NR : NR)), "Fq2 product column overflow");
+    const bool odd = rr_pair_odd();
+    Rr<P> px, py, nf, a1, b1;
+    rr_pair_swap(px, x.h);
+    rr_pair_swap(py, y.h);
+    rr_nr_times<P, NR>(nf, px);
+    rr_pair_select(a1, odd, px, x.h);     // * own y:      odd x0 y1, even x0 y0
+    rr_pair_select(b1, odd, x.h, nf);     // * partner y:  odd x1 y0, even (NR x1) y1
+    rr_mul2(r.h, a1, y.h, b1, py);
+}
+// NR = -1: complex squaring (fp2.tcc:141-151), c0 = (x0 + x1)(x0 - x1), c1 = x0 (2 x1): one Fq product per lane
+template <class P, int NR>
+AMDMSM_DEV void re_sqr(Rr2H<P, NR>& r, const Rr2H<P, NR>& x) {
+    if constexpr (NR == -1) {
+        const bool odd = rr_pair_odd();
+        Rr<P> px, s, d, a, b;
+        rr_pair_swap(px, x.h);
+        rr_add(s, x.h, px);
+        rr_sub(d, x.h, px);               // even lanes: x0 - x1
+        rr_add(b, x.h, x.h);              // odd lanes: 2 x1
+        rr_pair_select(a, odd, px, s);
+        rr_pair_select(b, odd, b, d);
+        if constexpr (!rr_fits<P>(4.0)) {  // both factors of the even lane carry B + 1 bits: 9 limbs of 29 bits do not hold that column
+            rr_norm(a, a);
+            rr_norm(b, b);
+        }
+        rr_mul(r.h, a, b);
+    } else {
+        re_mul(r, x, x);
+    }
+}
+// even: a0 b0 + (NR a1) b1 - c0 d0 - (NR c1) d1       odd: a0 b1 + a1 b0 - c0 d1 - c1 d0
+// one fused sum of four Fq products per lane where a column holds it, otherwise two sums of two and a carry step
+template <class P, int NR>
+AMDMSM_DEV void re_mul_sub_mul(Rr2H<P, NR>& r, const Rr2H<P, NR>& a, const Rr2H<P, NR>& b, const Rr2H<P, NR>& c, const Rr2H<P, NR>& d) {
+    constexpr int ANR = NR < 0 ? -NR : NR;
+    if constexpr (rr_fits<P>(2.0 * (1.0 + ANR))) {
+        const bool odd = rr_pair_odd();
+        Rr<P> pa, pb, pc, pd, nfa, nc, npc, kpc, t1, t2, t3, t4;
+        rr_pair_swap(pa, a.h);
+        rr_pair_swap(pb, b.h);
+        rr_pair_swap(pc, c.h);
+        rr_pair_swap(pd, d.h);
+        rr_nr_times<P, NR>(nfa, pa);
+        rr_neg(nc, c.h);
+        rr_neg(npc, pc);
+        rr_nr_times<P, -NR>(kpc, pc);
+        rr_pair_select(t1, odd, pa, a.h);     // * own b
+        rr_pair_select(t2, odd, a.h, nfa);    // * partner b
+        rr_pair_select(t3, odd, npc, nc);     // * own d      (odd: -c0 d1, even: -c0 d0)
+        rr_pair_select(t4, odd, nc, kpc);     // * partner d  (odd: -c1 d0, even: -(NR c1) d1)
+        const int32_t* const x[4] = {t1.v, t2.v, t3.v, t4.v};
+        const int32_t* const y[4] = {b.h.v, pb.v, d.h.v, pd.v};
+        rr_dot<P, 4>(r.h, x, y);
+    } else {
+        Rr2H<P, NR> u, v;
+        re_mul(u, a, b);
+        re_mul(v, c, d);
+        rr_sub(u.h, u.h, v.h);
+        rr_norm(r.h, u.h);
+    }
+}
+
+// ---- XYZZ accumulator in reduced radix ----------------------------------------------------------
+// x, y carry the Montgomery factor rho; zz, zzz carry rho * 2^D, so that a product with an affine
+// coordinate straight from memory (factor 2^(32N), fp.cuh form) lands on the factor rho:
+// (x2 2^(32N)) (zz rho 2^D) / rho = x2 zz rho.  Every other product of madd-2008-s keeps its
+// operands' factors (rho * rho / rho, rho 2^D * rho / rho).
+template <class E>
+struct XyzzRr {
+    E x, y, zz, zzz;
+};
+
+// the first point of a bucket: (x 2^D, y 2^D, 1, 1) in the factors above (values below 2^D p)
+template <class E, int N>
+AMDMSM_DEV void xyzz_rr_first(XyzzRr<E>& acc, const uint32_t (&wx)[N], const uint32_t (&wy)[N], bool neg) {
+    using P = typename re_info<E>::params;
     constexpr int D = rr_shape<P>::D;
     constexpr int BL = rr_shape<P>::B * rr_shape<P>::L;
-    rr_from_words<P, D>(acc.x, wx);
-    rr_from_words<P, D>(acc.y, wy);
-    rr_cneg(acc.y, acc.y, neg);
-    rr_set_const<P, rr_pow2<P, BL + D>>(acc.zz);
+    re_from_words<D>(acc.x, wx);
+    re_from_words<D>(acc.y, wy);
+    re_cneg(acc.y, acc.y, neg);
+    re_norm(acc.y, acc.y);   // limbs of -y back into [-1, 2^B): R = S2 - Y1 then stays within B bits (+ sign) like every other factor
+    re_set_pow2<BL + D>(acc.zz);
     acc.zzz = acc.zz;
 }
 
@@ -420,141 +585,123 @@ constexpr int rr_filter_k() {
     return (1 << rr_shape<P>::D) + 64;
 }
 
-// P == 0 (mod p): same x.  Same point -> 2 P (mdbl-2008-s-1, as xyzz_dbl_affine in ec.cuh; rare: equal
+// r = k * a for a small k, followed by a carry step (every factor of a product keeps limbs of B bits)
+template <class E>
+AMDMSM_DEV void re_small_times(E& r, const E& a, int k) {
+    using P = typename re_info<E>::params;
+    E t;
+#pragma unroll
+    for (int i = 0; i < rr_shape<P>::L; ++i) re_limb(t, i) = k * re_limb(a, i);
+    re_norm(r, t);
+}
+
+// P == 0: same x.  Same point -> 2 P (mdbl-2008-s-1, as xyzz_dbl_affine in ec.cuh; rare: equal
 // bases in one bucket), opposite points -> infinity.  Returns false when P != 0 after all (the filter
 // of the hot loop only looks at the low limb).
-template <class P>
-AMDMSM_DEV bool xyzz_rr_same_x(XyzzRr<P>& acc, bool& inf, const Rr<P>& pp, const Rr<P>& r, const uint32_t (&wx)[P::N],
-                               const uint32_t (&wy)[P::N], bool neg) {
-    constexpr int L = rr_shape<P>::L;
+template <class E, int N>
+AMDMSM_DEV bool xyzz_rr_same_x(XyzzRr<E>& acc, bool& inf, const E& pp, const E& r, const uint32_t (&wx)[N], const uint32_t (&wy)[N],
+                               bool neg) {
+    using P = typename re_info<E>::params;
     constexpr int D = rr_shape<P>::D;
-    constexpr int BL = rr_shape<P>::B * L;
-    if (!rr_is_zero_exact(pp)) return false;
-    if (!rr_is_zero_exact(r)) {   // opposite points
+    constexpr int BL = rr_shape<P>::B * rr_shape<P>::L;
+    if (!re_is_zero_exact(pp)) return false;
+    if (!re_is_zero_exact(r)) {   // opposite points
         inf = true;
         return true;
     }
-    // x, y with the factor rho (values below 2^D p); small multiples are followed by a carry step so
-    // that every factor of a product keeps limbs of B bits
-    Rr<P> x, y, v, w, s, m, t, c;
-    rr_from_words<P, D>(x, wx);
-    rr_from_words<P, D>(y, wy);
-    rr_cneg(y, y, neg);
-    rr_mul(t, y, y);
-#pragma unroll
-    for (int i = 0; i < L; ++i) t.v[i] *= 4;
-    rr_norm(v, t);              // V = (2Y)^2
-    rr_mul(t, y, v);
-#pragma unroll
-    for (int i = 0; i < L; ++i) t.v[i] *= 2;
-    rr_norm(w, t);              // W = 2Y V
-    rr_mul(s, x, v);            // S = X V
-    rr_mul(t, x, x);
-#pragma unroll
-    for (int i = 0; i < L; ++i) t.v[i] *= 3;
-    rr_norm(m, t);              // M = 3 X^2
-    rr_mul(t, m, m);
-#pragma unroll
-    for (int i = 0; i < L; ++i) t.v[i] -= 2 * s.v[i];
-    rr_norm(acc.x, t);          // X3 = M^2 - 2S
-    rr_sub(s, s, acc.x);
-    rr_neg(t, w);
-    rr_mul2(acc.y, m, s, t, y); // Y3 = M (S - X3) - W Y
-    rr_set_const<P, rr_pow2<P, BL + D>>(c);
-    rr_mul(acc.zz, v, c);       // factor rho -> rho 2^D
-    rr_mul(acc.zzz, w, c);
+    // x, y with the factor rho (values below 2^D p)
+    E x, y, v, w, s, m, t, c;
+    re_from_words<D>(x, wx);
+    re_from_words<D>(y, wy);
+    re_cneg(y, y, neg);
+    re_mul(t, y, y);
+    re_small_times(v, t, 4);    // V = (2Y)^2
+    re_mul(t, y, v);
+    re_small_times(w, t, 2);    // W = 2Y V
+    re_mul(s, x, v);            // S = X V
+    re_mul(t, x, x);
+    re_small_times(m, t, 3);    // M = 3 X^2
+    re_mul(t, m, m);
+    re_small_times(c, s, 2);
+    re_sub(t, t, c);
+    re_norm(acc.x, t);          // X3 = M^2 - 2S
+    re_sub(s, s, acc.x);
+    re_mul_sub_mul(acc.y, m, s, w, y);   // Y3 = M (S - X3) - W Y
+    re_set_pow2<BL + D>(c);
+    re_mul(acc.zz, v, c);       // factor rho -> rho 2^D
+    re_mul(acc.zzz, w, c);
     return true;
 }
 
-// acc += (wx, wy) (affine, canonical Montgomery words of fp.cuh; (0, 0) = infinity; neg: subtract).
-// madd-2008-s with the special-case ladder of G::mixed_add, as xyzz_madd (ec.cuh).
+// acc += (wx, wy) (affine, canonical Montgomery words of fp.cuh -- of this lane's component for an Fq2 pair;
+// (0, 0) = infinity; neg: subtract).  madd-2008-s with the special-case ladder of G::mixed_add, as xyzz_madd (ec.cuh).
 // mid() runs once, in uniform control flow, after the last use of wx / wy: the caller's hook to overwrite them
 // with the NEXT point (its loads then travel under the eight products that follow; the words cost no extra
 // registers, the limbs of this point are dead by then).
-template <class P, class Mid>
-AMDMSM_DEV void xyzz_madd_rr(XyzzRr<P>& acc, bool& inf, const uint32_t (&wx)[P::N], const uint32_t (&wy)[P::N], bool neg, Mid&& mid) {
+template <class E, int N, class Mid>
+AMDMSM_DEV void xyzz_madd_rr(XyzzRr<E>& acc, bool& inf, const uint32_t (&wx)[N], const uint32_t (&wy)[N], bool neg, Mid&& mid) {
+    using P = typename re_info<E>::params;
+    static_assert(N == P::N, "one component per lane");
     constexpr int L = rr_shape<P>::L;
     uint32_t any = 0;
 #pragma unroll
-    for (int i = 0; i < P::N; ++i) any |= wx[i] | wy[i];
+    for (int i = 0; i < N; ++i) any |= wx[i] | wy[i];
+    const bool p_inf = re_all<E>(any == 0);
     bool go = false;   // the general addition continues behind mid()
-    Rr<P> pp, r;
-    if (any != 0) {
+    E pp, r;
+    if (!p_inf) {
         if (inf) {
             xyzz_rr_first(acc, wx, wy, neg);
             inf = false;
         } else {
-            Rr<P> px, py;
-            rr_from_words<P, 0>(px, wx);
-            rr_from_words<P, 0>(py, wy);
-            rr_cneg(py, py, neg);
-            rr_mul(pp, px, acc.zz);     // U2
-            rr_mul(r, py, acc.zzz);     // S2
-            rr_sub(pp, pp, acc.x);      // P = U2 - X1
-            rr_sub(r, r, acc.y);        // R = S2 - Y1
+            E px, py;
+            re_from_words<0>(px, wx);
+            re_from_words<0>(py, wy);
+            re_cneg(py, py, neg);
+            re_mul(pp, px, acc.zz);     // U2
+            re_mul(r, py, acc.zzz);     // S2
+            re_sub(pp, pp, acc.x);      // P = U2 - X1
+            re_sub(r, r, acc.y);        // R = S2 - Y1
             go = true;
-            if (__builtin_expect(rr_maybe_zero<P, rr_filter_k<P>()>(pp), 0)) {
+            if (__builtin_expect(re_maybe_zero<rr_filter_k<P>()>(pp), 0)) {
                 if (xyzz_rr_same_x(acc, inf, pp, r, wx, wy, neg)) go = false;
             }
         }
     }
     mid();
     if (go) {
-        Rr<P> ppp, q, t;
-        rr_sqr(ppp, pp);                    // PP
-        rr_mul(q, acc.x, ppp);              // Q = X1 PP
-        rr_mul(acc.zz, acc.zz, ppp);        // ZZ3 = ZZ1 PP
-        rr_mul(ppp, pp, ppp);               // PPP = P PP
-        rr_mul(acc.zzz, acc.zzz, ppp);      // ZZZ3 = ZZZ1 PPP
-        rr_sqr(t, r);                       // R^2
+        E ppp, q, t;
+        re_sqr(ppp, pp);                    // PP
+        re_mul(q, acc.x, ppp);              // Q = X1 PP
+        re_mul(acc.zz, acc.zz, ppp);        // ZZ3 = ZZ1 PP
+        re_mul(ppp, pp, ppp);               // PPP = P PP
+        re_mul(acc.zzz, acc.zzz, ppp);      // ZZZ3 = ZZZ1 PPP
+        re_sqr(t, r);                       // R^2
 #pragma unroll
-        for (int i = 0; i < L; ++i) t.v[i] = t.v[i] - ppp.v[i] - 2 * q.v[i];   // X3 = R^2 - PPP - 2Q
-        rr_norm(acc.x, t);
-        rr_sub(q, q, acc.x);                // Q - X3
-        rr_neg(t, acc.y);
-        rr_mul2(acc.y, r, q, t, ppp);       // Y3 = R (Q - X3) - Y1 PPP
+        for (int i = 0; i < L; ++i) re_limb(t, i) = re_limb(t, i) - re_limb(ppp, i) - 2 * re_limb(q, i);   // X3 = R^2 - PPP - 2Q
+        re_norm(acc.x, t);
+        re_sub(q, q, acc.x);                // Q - X3
+        re_mul_sub_mul(acc.y, r, q, acc.y, ppp);   // Y3 = R (Q - X3) - Y1 PPP
     }
 }
-template <class P>
-AMDMSM_DEV void xyzz_madd_rr(XyzzRr<P>& acc, bool& inf, const uint32_t (&wx)[P::N], const uint32_t (&wy)[P::N], bool neg) {
-    xyzz_madd_rr<P>(acc, inf, wx, wy, neg, [] {});
+template <class E, int N>
+AMDMSM_DEV void xyzz_madd_rr(XyzzRr<E>& acc, bool& inf, const uint32_t (&wx)[N], const uint32_t (&wy)[N], bool neg) {
+    xyzz_madd_rr(acc, inf, wx, wy, neg, [] {});
 }
 
-// accumulator -> canonical (X, Y, ZZ, ZZZ) words of fp.cuh (factor 2^(32N)); all limbs zero (infinity) stay zero.
-// x 2^(32N) / rho drops the factor rho; zz carries 2^D more.
-template <class P>
-AMDMSM_DEV void xyzz_rr_export(uint32_t (&out)[4 * P::N], const XyzzRr<P>& a) {
+// One stored coordinate component (L limbs, factor rho 2^SH) -> canonical words of fp.cuh (factor 2^(32N));
+// zero limbs stay zero.  x 2^(32N - SH) / rho drops the factor.
+template <class P, int SH>
+AMDMSM_DEV void rr_export_component(uint32_t (&w)[P::N], const Rr<P>& a) {
     constexpr int L = rr_shape<P>::L;
     constexpr int B = rr_shape<P>::B;
-    constexpr int D = rr_shape<P>::D;
-    constexpr int N = P::N;
-    Rr<P> cx, cz, t;
+    constexpr int E = 32 * P::N - SH;
+    Rr<P> c, t;
 #pragma unroll
-    for (int i = 0; i < L; ++i) {
-        cx.v[i] = (32 * N) / B == i ? (int32_t)(1u << ((32 * N) % B)) : 0;
-        cz.v[i] = (32 * N - D) / B == i ? (int32_t)(1u << ((32 * N - D) % B)) : 0;
-    }
-    uint32_t w[N];
-    rr_mul(t, a.x, cx);
+    for (int i = 0; i < L; ++i) c.v[i] = E / B == i ? (int32_t)(1u << (E % B)) : 0;
+    rr_mul(t, a, c);
     rr_canon(t);
     rr_to_words<P>(w, t);
-#pragma unroll
-    for (int i = 0; i < N; ++i) out[i] = w[i];
-    rr_mul(t, a.y, cx);
-    rr_canon(t);
-    rr_to_words<P>(w, t);
-#pragma unroll
-    for (int i = 0; i < N; ++i) out[N + i] = w[i];
-    rr_mul(t, a.zz, cz);
-    rr_canon(t);
-    rr_to_words<P>(w, t);
-#pragma unroll
-    for (int i = 0; i < N; ++i) out[2 * N + i] = w[i];
-    rr_mul(t, a.zzz, cz);
-    rr_canon(t);
-    rr_to_words<P>(w, t);
-#pragma unroll
-    for (int i = 0; i < N; ++i) out[3 * N + i] = w[i];
 }
 
 }  // namespace amdmsm

@@ -13,6 +13,7 @@
 
 #include "curve_params.h"
 #include "ec.cuh"
+#include "fp2h.cuh"
 #include "rr.cuh"
 
 using namespace amdmsm;
@@ -25,7 +26,7 @@ __global__ void __launch_bounds__(256) k_check(const uint32_t* __restrict__ pts,
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     Xyzz<F> a;
     xyzz_set_inf(a);
-    XyzzRr<P> b;
+    XyzzRr<Rr<P>> b;
     rr_zero(b.x); rr_zero(b.y); rr_zero(b.zz); rr_zero(b.zzz);
     bool inf = true;
     for (int k = 0; k < len; ++k) {
@@ -43,7 +44,7 @@ __global__ void __launch_bounds__(256) k_check(const uint32_t* __restrict__ pts,
         for (int j = 0; j < N; ++j) { p.x.v[j] = wx[j]; p.y.v[j] = wy[j]; }
         fp_cneg(p.y, p.y, neg);
         xyzz_madd_lz(a, p);
-        xyzz_madd_rr<P>(b, inf, wx, wy, neg);
+        xyzz_madd_rr(b, inf, wx, wy, neg);
     }
     xyzz_canon(a);
     for (int j = 0; j < N; ++j) {
@@ -52,10 +53,70 @@ __global__ void __launch_bounds__(256) k_check(const uint32_t* __restrict__ pts,
         out32[i * 4 * N + 2 * N + j] = a.zz.v[j];
         out32[i * 4 * N + 3 * N + j] = a.zzz.v[j];
     }
-    uint32_t w[4 * N];
     if (inf) { rr_zero(b.x); rr_zero(b.y); rr_zero(b.zz); rr_zero(b.zzz); }
-    xyzz_rr_export<P>(w, b);
-    for (int j = 0; j < 4 * N; ++j) outrr[i * 4 * N + j] = w[j];
+    constexpr int D = rr_shape<P>::D;
+    uint32_t w[N];
+    rr_export_component<P, 0>(w, b.x);
+    for (int j = 0; j < N; ++j) outrr[i * 4 * N + j] = w[j];
+    rr_export_component<P, 0>(w, b.y);
+    for (int j = 0; j < N; ++j) outrr[i * 4 * N + N + j] = w[j];
+    rr_export_component<P, D>(w, b.zz);
+    for (int j = 0; j < N; ++j) outrr[i * 4 * N + 2 * N + j] = w[j];
+    rr_export_component<P, D>(w, b.zzz);
+    for (int j = 0; j < N; ++j) outrr[i * 4 * N + 3 * N + j] = w[j];
+}
+
+// Fq2 over lane pairs: the same comparison against xyzz_madd_lz on Fp2H (fp2h.cuh); thread t holds component t & 1 of
+// element pair t / 2, outputs per thread as (X, Y, ZZ, ZZZ) of its component
+template <class P, int NR>
+__global__ void __launch_bounds__(256) k_check2(const uint32_t* __restrict__ pts, size_t npts, int len, uint32_t* out32,
+                                                uint32_t* outrr) {
+    constexpr int N = P::N;
+    using F = Fp2H<P, NR>;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t i = t / 2;
+    const uint32_t comp = (uint32_t)(t & 1);
+    Xyzz<F> a;
+    xyzz_set_inf(a);
+    XyzzRr<Rr2H<P, NR>> b;
+    re_zero(b.x); re_zero(b.y); re_zero(b.zz); re_zero(b.zzz);
+    bool inf = true;
+    for (int k = 0; k < len; ++k) {
+        size_t idx = (i * 131 + (size_t)k * 7) % npts;
+        bool neg = ((i + k) & 1) != 0;
+        const int mode = (int)(i % 8);
+        if (mode == 1) { idx = (i * 131 + (size_t)(k / 2) * 7) % npts; neg = false; }
+        if (mode == 2) { idx = (i * 131 + (size_t)(k / 2) * 7) % npts; neg = (k & 1) != 0; }
+        // an Fq2 affine point = 4 N words (x.c0, x.c1, y.c0, y.c1): two consecutive records of the Fq table
+        const uint32_t* rec = pts + (idx / 2) * 4 * N;
+        uint32_t wx[N], wy[N];
+        for (int j = 0; j < N; ++j) { wx[j] = rec[comp * N + j]; wy[j] = rec[2 * N + comp * N + j]; }
+        if (mode == 3 && k % 3 == 1) { for (int j = 0; j < N; ++j) wx[j] = wy[j] = 0; }
+        if (mode == 4 && k % 3 == 1 && comp == 1) { for (int j = 0; j < N; ++j) wx[j] = wy[j] = 0; }   // a zero component, not infinity
+        Aff<F> p;
+        for (int j = 0; j < N; ++j) { p.x.h.v[j] = wx[j]; p.y.h.v[j] = wy[j]; }
+        el_cneg(p.y, p.y, neg);
+        xyzz_madd_lz(a, p);
+        xyzz_madd_rr(b, inf, wx, wy, neg);
+    }
+    xyzz_canon(a);
+    for (int j = 0; j < N; ++j) {
+        out32[t * 4 * N + j] = a.x.h.v[j];
+        out32[t * 4 * N + N + j] = a.y.h.v[j];
+        out32[t * 4 * N + 2 * N + j] = a.zz.h.v[j];
+        out32[t * 4 * N + 3 * N + j] = a.zzz.h.v[j];
+    }
+    if (inf) { re_zero(b.x); re_zero(b.y); re_zero(b.zz); re_zero(b.zzz); }
+    constexpr int D = rr_shape<P>::D;
+    uint32_t w[N];
+    rr_export_component<P, 0>(w, b.x.h);
+    for (int j = 0; j < N; ++j) outrr[t * 4 * N + j] = w[j];
+    rr_export_component<P, 0>(w, b.y.h);
+    for (int j = 0; j < N; ++j) outrr[t * 4 * N + N + j] = w[j];
+    rr_export_component<P, D>(w, b.zz.h);
+    for (int j = 0; j < N; ++j) outrr[t * 4 * N + 2 * N + j] = w[j];
+    rr_export_component<P, D>(w, b.zzz.h);
+    for (int j = 0; j < N; ++j) outrr[t * 4 * N + 3 * N + j] = w[j];
 }
 
 template <class P, int WAVES>
@@ -84,7 +145,7 @@ __global__ void __launch_bounds__(256, WAVES) k_timerr(const uint32_t* __restric
     constexpr int N = P::N;
     constexpr int L = rr_shape<P>::L;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    XyzzRr<P> b;
+    XyzzRr<Rr<P>> b;
     rr_zero(b.x); rr_zero(b.y); rr_zero(b.zz); rr_zero(b.zzz);
     bool inf = true;
     for (int k = 0; k < len; ++k) {
@@ -92,14 +153,14 @@ __global__ void __launch_bounds__(256, WAVES) k_timerr(const uint32_t* __restric
         uint32_t wx[N], wy[N];
 #pragma unroll
         for (int j = 0; j < N; ++j) { wx[j] = pts[idx * 2 * N + j]; wy[j] = pts[idx * 2 * N + N + j]; }
-        xyzz_madd_rr<P>(b, inf, wx, wy, ((i + k) & 1) != 0);
+        xyzz_madd_rr(b, inf, wx, wy, ((i + k) & 1) != 0);
     }
     uint32_t x = inf;
     for (int j = 0; j < L; ++j) x ^= (uint32_t)(b.x.v[j] ^ b.y.v[j] ^ b.zz.v[j] ^ b.zzz.v[j]);
     out[i] = x;
 }
 
-template <class P, int W32, int WRR>
+template <class P, int W32, int WRR, int NR2 = 0>
 int run(const char* name) {
     constexpr int N = P::N;
     const size_t npts = 1 << 16;
@@ -141,6 +202,31 @@ int run(const char* name) {
         printf("%s: len %2d: %d mismatches of %zu lanes\n", name, len, mism, lanes);
         bad += mism;
     }
+    if constexpr (NR2 != 0) {
+        for (int len : {1, 2, 3, 4, 7, 24}) {
+            hipLaunchKernelGGL((k_check2<P, NR2>), dim3(lanes / 256), dim3(256), 0, 0, dp, npts, len, o32, orr);
+            std::vector<uint32_t> a(lanes * 4 * N), b(lanes * 4 * N);
+            hipMemcpy(a.data(), o32, a.size() * 4, hipMemcpyDeviceToHost);
+            hipMemcpy(b.data(), orr, b.size() * 4, hipMemcpyDeviceToHost);
+            int mism = 0;
+            for (size_t i = 0; i < lanes; ++i) {
+                bool eq = true;
+                for (int j = 0; j < 4 * N; ++j) eq &= a[i * 4 * N + j] == b[i * 4 * N + j];
+                if (!eq) {
+                    if (mism < 3) {
+                        printf("  Fq2 mismatch thread %zu (pair mode %zu, component %zu) len %d\n   32: ", i, (i / 2) % 8, i & 1, len);
+                        for (int j = 0; j < 4 * N; ++j) printf("%08x ", a[i * 4 * N + j]);
+                        printf("\n   rr: ");
+                        for (int j = 0; j < 4 * N; ++j) printf("%08x ", b[i * 4 * N + j]);
+                        printf("\n");
+                    }
+                    ++mism;
+                }
+            }
+            printf("%s, Fq2 (u^2 = %d) on lane pairs: len %2d: %d mismatches of %zu threads\n", name, NR2, len, mism, lanes);
+            bad += mism;
+        }
+    }
     // timing: one round of resident waves at the kernel's occupancy
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
@@ -178,14 +264,14 @@ int main(int argc, char** argv) {
 #endif
     (void)all;
 #if PROTO_FIELD == 1
-    bad += run<alt_bn128_fq, 4, 4>("alt_bn128 Fq");
+    bad += run<alt_bn128_fq, 4, 4, -1>("alt_bn128 Fq");
     bad += run<alt_bn128_fq, 4, 3>("alt_bn128 Fq");
     bad += run<alt_bn128_fq, 4, 2>("alt_bn128 Fq");
 #elif PROTO_FIELD == 2
-    bad += run<bls12_377_fq, 3, 3>("bls12_377 Fq");
+    bad += run<bls12_377_fq, 3, 3, -5>("bls12_377 Fq");
     bad += run<bls12_377_fq, 3, 2>("bls12_377 Fq");
 #elif PROTO_FIELD == 3
-    bad += run<bls12_381_fq, 3, 2>("bls12_381 Fq");
+    bad += run<bls12_381_fq, 3, 2, -1>("bls12_381 Fq");
 #else
     bad += run<bw6_761_fq, 2, 2>("bw6_761 Fq");
 #endif
