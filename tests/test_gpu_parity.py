@@ -668,3 +668,23 @@ def test_lane_split_arithmetic_selftest(tmp_path):
                    timeout=600)
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "WIDE TEST PASSED" in r.stdout, r.stdout[-3000:]
+
+
+@pytest.mark.parametrize("field", [1, 2, 3, 4], ids=["alt_bn128", "bls12_377", "bls12_381", "bw6_761"])
+def test_reduced_radix_accumulation_selftest(tmp_path, field):
+    """tools/proto_rr.hip: the reduced-radix mixed addition of k_accumulate (libff_amd/csrc/rr.cuh: Fq per lane, Fq2 over
+    lane pairs) against the 32-bit-word implementation (ec.cuh xyzz_madd_lz, fp2h.cuh), word for word after export, on
+    random field elements and on operands at the edges of the limb range, with equal / opposite / infinite points in
+    the sequences.  Built on the box."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    exe = tmp_path / "proto_rr"
+    subprocess.run([hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", f"-DPROTO_FIELD={field}", "-Wno-unused-value",
+                    "-Wno-unused-result", "-Wno-pass-failed", "-I" + os.path.join(REPO, "libff_amd", "csrc"),
+                    "-I" + os.path.join(REPO, "include"), os.path.join(REPO, "tools", "proto_rr.hip"), "-o", str(exe)],
+                   check=True, capture_output=True, timeout=900)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "all equal" in r.stdout and "mismatch lane" not in r.stdout, r.stdout[-3000:]
