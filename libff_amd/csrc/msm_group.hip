@@ -969,16 +969,20 @@ struct acc_state {
 AMDMSM_DEV void acc_reset(acc_state& s) { s.inf = true; }   // the limbs are dead while inf is set
 // the record as it is: this lane's 4 L limbs (all zero: infinity); k_rr_export makes canonical words of it
 AMDMSM_DEV void acc_store(uint32_t* q, const acc_state& s) {
-    const int32_t keep = s.inf ? 0 : -1;
+    uint4* q4 = reinterpret_cast<uint4*>(q + (GP::DEG == 2 && (threadIdx.x & 1u) ? 4 * RRL : 0));
+    if (__builtin_expect(s.inf, 0)) {   // a bucket whose points cancelled (or a piece with infinite bases only)
+#pragma unroll
+        for (int i = 0; i < RRL; ++i) q4[i] = make_uint4(0, 0, 0, 0);
+        return;
+    }
     uint32_t w[4 * RRL];
 #pragma unroll
     for (int i = 0; i < RRL; ++i) {
-        w[i] = (uint32_t)(re_limb(s.a.x, i) & keep);
-        w[RRL + i] = (uint32_t)(re_limb(s.a.y, i) & keep);
-        w[2 * RRL + i] = (uint32_t)(re_limb(s.a.zz, i) & keep);
-        w[3 * RRL + i] = (uint32_t)(re_limb(s.a.zzz, i) & keep);
+        w[i] = (uint32_t)re_limb(s.a.x, i);
+        w[RRL + i] = (uint32_t)re_limb(s.a.y, i);
+        w[2 * RRL + i] = (uint32_t)re_limb(s.a.zz, i);
+        w[3 * RRL + i] = (uint32_t)re_limb(s.a.zzz, i);
     }
-    uint4* q4 = reinterpret_cast<uint4*>(q + (GP::DEG == 2 && (threadIdx.x & 1u) ? 4 * RRL : 0));
 #pragma unroll
     for (int i = 0; i < RRL; ++i) q4[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
 }

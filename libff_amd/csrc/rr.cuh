@@ -689,18 +689,64 @@ AMDMSM_DEV void xyzz_madd_rr(XyzzRr<E>& acc, bool& inf, const uint32_t (&wx)[N],
     xyzz_madd_rr(acc, inf, wx, wy, neg, [] {});
 }
 
-// One stored coordinate component (L limbs, factor rho 2^SH) -> canonical words of fp.cuh (factor 2^(32N));
-// zero limbs stay zero.  x 2^(32N - SH) / rho drops the factor.
-template <class P, int SH>
-AMDMSM_DEV void rr_export_component(uint32_t (&w)[P::N], const Rr<P>& a) {
+// r = a * 2^E / rho: the product scan with a one-limb second factor -- one multiply per column in the multiplication
+// half instead of up to L (k_rr_export runs four of these per record)
+template <class P, int E, int K>
+AMDMSM_DEV void rr_mulp2_column(int64_t& acc, int32_t* m, int32_t* t, const int32_t* a) {
     constexpr int L = rr_shape<P>::L;
     constexpr int B = rr_shape<P>::B;
-    constexpr int E = 32 * P::N - SH;
-    Rr<P> c, t;
+    constexpr uint32_t M = rr_shape<P>::M;
+    constexpr uint32_t NINV = P::INV & M;
+    constexpr int J = E / B, S = E % B;
+    static_assert(J < L, "2^E must lie below rho");
+    if constexpr (K - J >= 0 && K - J < L) rr_chain<1>::vs(acc, a[K - J], (int32_t)(1u << S));
+    if constexpr (K < L) {
+        rr_col_mp<P, K, 0, K>(acc, m);
+        m[K] = (int32_t)(((uint32_t)acc * NINV) & M);
+        rr_col_mp<P, K, K, 1>(acc, m);
+    } else {
+        rr_col_mp<P, K, K - L + 1, 2 * L - 1 - K>(acc, m);
+        t[K - L] = (int32_t)((uint32_t)acc & M);
+    }
+    acc >>= B;
+    if constexpr (K + 1 < 2 * L - 1) rr_mulp2_column<P, E, K + 1>(acc, m, t, a);
+}
+template <class P, int E>
+AMDMSM_DEV void rr_mul_pow2(Rr<P>& r, const Rr<P>& a) {
+    constexpr int L = rr_shape<P>::L;
+    int32_t m[L], t[L];
+    int64_t acc = 0;
+    rr_mulp2_column<P, E, 0>(acc, m, t, a.v);
+    t[L - 1] = (int32_t)acc;
 #pragma unroll
-    for (int i = 0; i < L; ++i) c.v[i] = E / B == i ? (int32_t)(1u << (E % B)) : 0;
-    rr_mul(t, a, c);
-    rr_canon(t);
+    for (int i = 0; i < L; ++i) r.v[i] = t[i];
+}
+// a product's output (limbs 0..L-2 in [0, 2^B), the sign in the top limb) of value in (-p, 2p) -> canonical [0, p):
+// a + p and a - p with one carry pass each, chosen by the signs
+template <class P>
+AMDMSM_DEV void rr_canon_product(Rr<P>& a) {
+    constexpr int L = rr_shape<P>::L;
+    Rr<P> u, d;
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+        u.v[i] = a.v[i] + (int32_t)rr_tab<P>::PL.v[i];
+        d.v[i] = a.v[i] - (int32_t)rr_tab<P>::PL.v[i];
+    }
+    rr_ripple(u);
+    rr_ripple(d);
+    const bool neg = a.v[L - 1] < 0, ge = d.v[L - 1] >= 0;
+#pragma unroll
+    for (int i = 0; i < L; ++i) a.v[i] = neg ? u.v[i] : (ge ? d.v[i] : a.v[i]);
+}
+
+// One stored coordinate component (L limbs, factor rho 2^SH, magnitude below 2^SH p... 2^D p for x and y) -> canonical
+// words of fp.cuh (factor 2^(32N)); zero limbs stay zero.  a 2^(32N - SH) / rho drops the factor and leaves a value in
+// (-p, 2p).
+template <class P, int SH>
+AMDMSM_DEV void rr_export_component(uint32_t (&w)[P::N], const Rr<P>& a) {
+    Rr<P> t;
+    rr_mul_pow2<P, 32 * P::N - SH>(t, a);
+    rr_canon_product(t);
     rr_to_words<P>(w, t);
 }
 
