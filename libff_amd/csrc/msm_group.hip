@@ -2520,6 +2520,73 @@ __global__ void __launch_bounds__(TPB) k_madd_bench(const uint32_t* __restrict__
     store_jac(out + i * XYZW, acc);
 }
 
+#if AMDMSM_ACC_RR
+// The same on reduced-radix limbs (rr.cuh) for the groups with coordinates in Fq: one loop over the windows (the
+// scalar is shifted down window by window, so the mixed addition is emitted once), the accumulator exported to
+// canonical words at the end -- in uniform control flow, once per lane.  window < 32.
+template <class G>   // G = GP; a template only so that the Fq2 groups do not instantiate it
+__global__ void __launch_bounds__(TPB, 2) k_fb_exp_rr(const uint32_t* __restrict__ table_aff, const uint32_t* __restrict__ scalars,
+                                                      size_t n, int mont, const uint32_t* __restrict__ coeff, int scalar_size,
+                                                      int window, int form, uint32_t* __restrict__ out) {
+    static_assert(G::DEG == 1, "prime-field groups");
+    using FQ = typename G::fq;
+    using E = Fp<FQ, (AMDMSM_COLD_INLINE != 0)>;
+    const size_t i = gtid();
+    if (i >= n) return;
+    Fp<FR> x;
+    fp_load(x, scalars + i * FRW);
+    if (coeff) {   // coeff * v[i] (batch_exp_with_coeff, multiexp.tcc:937)
+        Fp<FR> cf;
+        fp_load(cf, coeff);
+        if (!mont) {
+            fp_to_mont(x, x);
+            fp_to_mont(cf, cf);
+        }
+        fp_mul(x, x, cf);
+        fp_from_mont(x, x);
+    } else if (mont) {
+        fp_from_mont(x, x);
+    }
+    const int outerc = (scalar_size + window - 1) / window;
+    const size_t row_len = (size_t)1 << window;
+    const uint32_t wmask = (1u << window) - 1u;
+    XyzzRr<Rr<FQ>> acc;
+    rr_zero(acc.x); rr_zero(acc.y); rr_zero(acc.zz); rr_zero(acc.zzz);
+    bool inf = true;   // powers_of_g[0][0] = zero
+    aff_words e;
+    // the entry of window `outer` (digit 0 names the zero entry: an all-zero record is skipped by the addition as an
+    // infinite point); the scalar is shifted down as its digits are taken
+    auto fetch = [&](int outer) {
+        const uint32_t inner = x.v[0] & wmask;
+#pragma unroll
+        for (int j = 0; j < FRW; ++j) x.v[j] = __builtin_amdgcn_alignbit(j + 1 < FRW ? x.v[j + 1] : 0u, x.v[j], (uint32_t)window);
+#pragma unroll
+        for (int j = 0; j < FQ::N; ++j) e.x[j] = e.y[j] = 0;
+        if (inner) aff_words_load(e, table_aff + ((size_t)outer * row_len + inner) * AFFW);
+    };
+    fetch(0);
+    for (int outer = 0; outer < outerc; ++outer) {
+        // the next entry travels under the second half of this addition (xyzz_madd_rr's mid hook)
+        xyzz_madd_rr(acc, inf, e.x, e.y, false, [&] {
+            if (outer + 1 < outerc) fetch(outer + 1);
+        });
+    }
+    constexpr int D = rr_shape<FQ>::D;
+    Xyzz<E> a;
+    if (inf) {
+        xyzz_set_inf(a);
+    } else {
+        rr_export_component<FQ, 0>(a.x.v, acc.x);
+        rr_export_component<FQ, 0>(a.y.v, acc.y);
+        rr_export_component<FQ, D>(a.zz.v, acc.zz);
+        rr_export_component<FQ, D>(a.zzz.v, acc.zzz);
+    }
+    Jac<E> res;
+    xyzz_to_jac(res, a);
+    store_out(out + i * XYZW, res, form);
+}
+#endif
+
 // ---------------------------------------------------------------- launchers
 inline unsigned blocks_for(size_t n, int tpb = TPB) { return (unsigned)((n + tpb - 1) / tpb); }
 
@@ -2751,6 +2818,20 @@ void l_disk_decode_compressed(hipStream_t st, const uint32_t* src, size_t n, uin
 // table: outerc * 2^window Jacobian points of scratch, gouter: outerc points, table_aff: outerc * 2^window
 // compact affine records (what k_fb_exp reads).  build_table = 0: table_aff already holds the table of this
 // (g, scalar_size, window) -- the caller keeps it between calls.
+#if AMDMSM_ACC_RR
+template <class G>
+bool launch_fb_exp_rr(hipStream_t st, const uint32_t* table_aff, const uint32_t* scalars, size_t n, int mont, const uint32_t* coeff,
+                      int scalar_size, int window, int form, uint32_t* out) {
+    if constexpr (G::DEG == 1) {
+        if (window < 32) {
+            hipLaunchKernelGGL(k_fb_exp_rr<G>, dim3(blocks_for(n)), dim3(TPB), 0, st, table_aff, scalars, n, mont, coeff, scalar_size,
+                               window, form, out);
+            return true;
+        }
+    }
+    return false;
+}
+#endif
 void l_fixed_base_exp(hipStream_t st, const uint32_t* g_xyz, int scalar_size, int window, const uint32_t* scalars, size_t n,
                       int mont, const uint32_t* coeff, int form, uint32_t* gouter, uint32_t* table, uint32_t* table_aff,
                       int build_table, uint32_t* out) {
@@ -2769,6 +2850,9 @@ void l_fixed_base_exp(hipStream_t st, const uint32_t* g_xyz, int scalar_size, in
                            entries, table_aff);
     }
     if (n) {
+#if AMDMSM_ACC_RR
+        if (launch_fb_exp_rr<GP>(st, table_aff, scalars, n, mont, coeff, scalar_size, window, form, out)) return;
+#endif
         hipLaunchKernelGGL(k_fb_exp, dim3(blocks_for(n)), dim3(TPB), 0, st, table_aff, scalars, n, mont, coeff, scalar_size,
                            window, form, out);
     }

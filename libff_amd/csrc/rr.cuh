@@ -346,29 +346,6 @@ AMDMSM_DEV void rr_ripple(Rr<P>& a) {
     }
     a.v[L - 1] += carry;
 }
-// value in (-2p, 3p) -> canonical [0, p), limbs normalised
-template <class P>
-AMDMSM_DEV void rr_canon(Rr<P>& a) {
-    constexpr int L = rr_shape<P>::L;
-    rr_ripple(a);
-#pragma unroll
-    for (int rep = 0; rep < 2; ++rep) {
-        const int32_t neg = a.v[L - 1] < 0 ? -1 : 0;
-#pragma unroll
-        for (int i = 0; i < L; ++i) a.v[i] += (int32_t)rr_tab<P>::PL.v[i] & neg;
-        rr_ripple(a);
-    }
-#pragma unroll
-    for (int rep = 0; rep < 2; ++rep) {
-        Rr<P> d;
-#pragma unroll
-        for (int i = 0; i < L; ++i) d.v[i] = a.v[i] - (int32_t)rr_tab<P>::PL.v[i];
-        rr_ripple(d);
-        const bool ge = d.v[L - 1] >= 0;
-#pragma unroll
-        for (int i = 0; i < L; ++i) a.v[i] = ge ? d.v[i] : a.v[i];
-    }
-}
 // canonical limbs -> N words
 template <class P>
 AMDMSM_DEV void rr_to_words(uint32_t (&w)[P::N], const Rr<P>& a) {
