@@ -319,7 +319,7 @@ int make_plan(const group_vtable *vt, size_t n, int c_req, int L_req, plan_t &p,
     p.L = L;
     const size_t xyz_bytes = (size_t)3 * vt->el_words * 4;
     p.list_stride = align_up(n ? n : 1, 64) + 16;   // + one chunk: a lane's last staged read may run past its entries
-    // entries per lane S (<= 128; lane t of a window owns entries [t*S, (t+1)*S)).  All lanes do the
+    // entries per lane S (<= 128, 256 in long launches; lane t of a window owns entries [t*S, (t+1)*S)).  All lanes do the
     // same work and the device holds `resident` of them at once, so the lane count W*T should
     // fill whole rounds: k rounds exactly for the smallest k that keeps S <= 128, or simply
     // S = 128 once there are many rounds anyway.
@@ -327,7 +327,12 @@ int make_plan(const group_vtable *vt, size_t n, int c_req, int L_req, plan_t &p,
         const double resident = (double)vt->accumulate_resident_lanes(overlap ? 1 : 0);
         const double entries = (double)n * p.W;
         uint32_t S = 8;
-        if (entries >= 8.0 * 128.0 * resident) {
+        if (entries >= 4.0 * 256.0 * resident) {
+            // many rounds: longer lanes halve the partial records the fix-up and the export pass handle
+            // (alt_bn128 G1, AMDMSM_ACC_S = 128 / 192 / 256 / 384 / 512: 2^26 75.5 / 74.8 / 74.0 / 74.1 / 74.6 ms,
+            //  2^24 22.7 / 22.9 / 22.3 / 23.0 / 23.2 ms)
+            S = 256;
+        } else if (entries >= 8.0 * 128.0 * resident) {
             S = 128;
         } else if (entries > 8.0 * resident) {
             uint32_t k = 1;
