@@ -586,6 +586,16 @@ AMDMSM_DEV bool xyzz_rr_same_x(XyzzRr<E>& acc, bool& inf, const E& pp, const E& 
         inf = true;
         return true;
     }
+    {   // a point of order two (y == 0; the cofactor curves have them) doubles to infinity: ZZ = (2y)^2 would be a zero
+        // the loop has no test for -- the 32-bit form notices it as zz == 0
+        uint32_t any_y = 0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) any_y |= wy[i];
+        if (re_all<E>(any_y == 0)) {
+            inf = true;
+            return true;
+        }
+    }
     // x, y with the factor rho (values below 2^D p)
     E x, y, v, w, s, m, t, c;
     re_from_words<D>(x, wx);

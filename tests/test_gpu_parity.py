@@ -688,3 +688,41 @@ def test_reduced_radix_accumulation_selftest(tmp_path, field):
                    check=True, capture_output=True, timeout=900)
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "all equal" in r.stdout and "mismatch lane" not in r.stdout, r.stdout[-3000:]
+
+
+@pytest.mark.parametrize("name,curve,group,x_plain", [("bls12_377_g1", 1, 1, -1), ("bw6_761_g1", 2, 1, 1)])
+def test_points_of_order_two_in_one_bucket(engine, port, name, curve, group, x_plain):
+    """The cofactor curves carry points of order two -- (-1, 0) on y^2 = x^3 + 1 (bls12_377 G1), (1, 0) on y^2 = x^3 - 1
+    (bw6_761 G1) -- which libff's multi_exp accepts like any other base.  Two of them with equal scalars meet in one
+    bucket: the mixed addition's doubling branch must give infinity (2 T = 0; mixed_add -> dbl, e.g. bls12_377_g1.cpp:
+    208-283), which the reduced-radix loop decides from y == 0 where the 32-bit form saw ZZ == 0."""
+    g = golden()
+    q = to_int(g[f"{name}/fq_modulus"])
+    nq = len(g[f"{name}/fq_modulus"])   # 64-bit limbs
+    r_mont = (1 << (64 * nq)) % q
+
+    def limbs(v):
+        return [(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(nq)]
+
+    t = np.array(limbs((x_plain * r_mont) % q) + limbs(0) + limbs(r_mont), dtype=np.uint64)   # (X, Y, Z) = (x, 0, 1), Montgomery form
+    _, zero = port.group_consts(curve, group)
+    assert port.group_op(curve, group, 6, port.group_op(curve, group, 2, t), zero) != 0, "2 T must be zero for the reference"
+    n = 40
+    bases = port.bases_seq(curve, group, n, first=3)
+    sc = port.scalars_sha512(curve, 77, n)
+    for i in (4, 9, 17, 30):   # four copies of T with one scalar, one more with another
+        bases[i] = t
+        sc[i] = sc[4]
+    bases[33] = t
+    want = port.multi_exp(curve, group, bases, sc, port.BDLO12_SIGNED, 1)
+    for c in (0, 4, 8):
+        got = engine.multi_exp(curve, group, bases, sc, base_form=multi_exp_base_form_special, window_bits=c)
+        assert (got == want).all(), c
+    # the fixed-size pattern of the bench, with the order-two point spread through a larger input
+    n = 3000
+    bases = port.bases_seq(curve, group, n, first=1)
+    sc = port.scalars_sha512(curve, 78, n)
+    bases[::7] = t
+    sc[::7] = sc[0]
+    want = port.multi_exp(curve, group, bases, sc, port.BDLO12_SIGNED, 1)
+    assert (engine.multi_exp(curve, group, bases, sc, base_form=multi_exp_base_form_special) == want).all()
