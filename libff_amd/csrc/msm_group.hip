@@ -2356,8 +2356,83 @@ AMDMSM_DEV bool lattice_subgroup_check(const Aff<E>& a) {
     return jac_is_inf(t);
 }
 
+#if AMDMSM_ACC_RR
+// The same two tests on reduced-radix limbs (rr.cuh jac_dbl_rr / jac_madd_rr) for the groups with coordinates in Fq:
+// the chains are 128-380 doublings long, every lane on the same scalar, and run at the multiply-issue rate.
+template <class G>   // G = GP; templates so that the Fq2 groups do not instantiate them
+AMDMSM_DEV bool endo_subgroup_check_rr(const uint32_t (&wx)[FQ::N], const uint32_t (&wy)[FQ::N]) {
+    using R = Rr<typename G::fq>;
+    R px, py, sx, beta;
+    re_from_words_rho(px, wx);
+    re_from_words_rho(py, wy);
+    re_from_words_rho(beta, G::ENDO_BETA);
+    re_mul(sx, px, beta);   // sigma(x, y) = (beta x, y)
+    JacRr<R> t;
+    bool inf = true;
+    for (int i = 4 * 32 - 1; i >= 0; --i) {   // [c1] sigma(P), most significant bit first (curve_utils.tcc:14-32)
+        uint32_t w = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w = ((i >> 5) == j) ? G::ENDO_C1[j] : w;
+        jac_dbl_rr(t, inf);
+        if ((w >> (i & 31)) & 1u) jac_madd_rr(t, inf, sx, py);
+    }
+    jac_madd_rr(t, inf, px, py);
+    return jac_is_inf_rr(t, inf);
+}
+template <class G>
+AMDMSM_DEV bool lattice_subgroup_check_rr(const uint32_t (&wx)[FQ::N], const uint32_t (&wy)[FQ::N]) {
+    using R = Rr<typename G::fq>;
+    R p1x, p2x, py, ny, beta;
+    re_from_words_rho(p1x, wx);
+    re_from_words_rho(py, wy);
+    re_from_words_rho(beta, G::GLV_BETA);
+    re_mul(p2x, p1x, beta);   // phi(x, y) = (beta x, y)
+    re_neg(ny, py);
+    re_norm(ny, ny);
+    JacRr<R> t;
+    bool inf = true;
+    for (int i = GLV::SUB_BITS - 1; i >= 0; --i) {
+        jac_dbl_rr(t, inf);
+        const int wd = i >> 5;
+        const uint32_t m = 1u << (i & 31);
+        if (GLV::SUB_A_POS[wd] & m) jac_madd_rr(t, inf, p1x, py);
+        if (GLV::SUB_A_NEG[wd] & m) jac_madd_rr(t, inf, p1x, ny);
+        if (GLV::SUB_B_POS[wd] & m) jac_madd_rr(t, inf, p2x, py);
+        if (GLV::SUB_B_NEG[wd] & m) jac_madd_rr(t, inf, p2x, ny);
+    }
+    return jac_is_inf_rr(t, inf);
+}
+template <class G, class A>   // A = Aff<E>: a template parameter so that a.x.v is only looked up where DEG == 1
+AMDMSM_DEV bool in_safe_subgroup_rr(const A& a, bool& done) {
+    done = false;
+    if constexpr (G::DEG == 1) {
+#ifndef AMDMSM_SUBGROUP_BY_ORDER
+        if constexpr (G::SUBGROUP_CHECK == 2 || G::SUBGROUP_CHECK == 3) {
+            uint32_t wx[FQ::N], wy[FQ::N];
+#pragma unroll
+            for (int j = 0; j < FQ::N; ++j) {
+                wx[j] = a.x.v[j];
+                wy[j] = a.y.v[j];
+            }
+            done = true;
+            if constexpr (G::SUBGROUP_CHECK == 2) return endo_subgroup_check_rr<G>(wx, wy);
+            else return lattice_subgroup_check_rr<G>(wx, wy);
+        }
+#endif
+    }
+    return false;
+}
+#endif
+
 AMDMSM_DEV bool in_safe_subgroup(const Aff<E>& a) {
     if (GP::SUBGROUP_CHECK == 0) return true;   // alt_bn128_g1.cpp:359-363
+#if AMDMSM_ACC_RR
+    {
+        bool done;
+        const bool ok = in_safe_subgroup_rr<GP>(a, done);
+        if (done) return ok;
+    }
+#endif
 #ifndef AMDMSM_SUBGROUP_BY_ORDER
     if (GP::SUBGROUP_CHECK == 3) return lattice_subgroup_check(a);
 #endif

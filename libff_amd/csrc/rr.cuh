@@ -416,11 +416,13 @@ AMDMSM_DEV bool re_all(bool mine) {
 
 // component-wise operations
 template <class P> AMDMSM_DEV void re_sub(Rr<P>& r, const Rr<P>& a, const Rr<P>& b) { rr_sub(r, a, b); }
+template <class P> AMDMSM_DEV void re_add(Rr<P>& r, const Rr<P>& a, const Rr<P>& b) { rr_add(r, a, b); }
 template <class P> AMDMSM_DEV void re_neg(Rr<P>& r, const Rr<P>& a) { rr_neg(r, a); }
 template <class P> AMDMSM_DEV void re_cneg(Rr<P>& r, const Rr<P>& a, bool n) { rr_cneg(r, a, n); }
 template <class P> AMDMSM_DEV void re_norm(Rr<P>& r, const Rr<P>& a) { rr_norm(r, a); }
 template <class P> AMDMSM_DEV void re_zero(Rr<P>& r) { rr_zero(r); }
 template <class P, int NR> AMDMSM_DEV void re_sub(Rr2H<P, NR>& r, const Rr2H<P, NR>& a, const Rr2H<P, NR>& b) { rr_sub(r.h, a.h, b.h); }
+template <class P, int NR> AMDMSM_DEV void re_add(Rr2H<P, NR>& r, const Rr2H<P, NR>& a, const Rr2H<P, NR>& b) { rr_add(r.h, a.h, b.h); }
 template <class P, int NR> AMDMSM_DEV void re_neg(Rr2H<P, NR>& r, const Rr2H<P, NR>& a) { rr_neg(r.h, a.h); }
 template <class P, int NR> AMDMSM_DEV void re_cneg(Rr2H<P, NR>& r, const Rr2H<P, NR>& a, bool n) { rr_cneg(r.h, a.h, n); }
 template <class P, int NR> AMDMSM_DEV void re_norm(Rr2H<P, NR>& r, const Rr2H<P, NR>& a) { rr_norm(r.h, a.h); }
@@ -735,6 +737,110 @@ AMDMSM_DEV void rr_export_component(uint32_t (&w)[P::N], const Rr<P>& a) {
     rr_mul_pow2<P, 32 * P::N - SH>(t, a);
     rr_canon_product(t);
     rr_to_words<P>(w, t);
+}
+
+// ---- Jacobian points in reduced radix (the per-point subgroup tests of the FFI decoder: long double-and-add chains,
+// every lane on the same scalar) -- X, Y, Z all carry the factor rho, infinity is a flag kept beside the point ----
+template <class E>
+struct JacRr {
+    E x, y, z;
+};
+// canonical words with the factor 2^(32N) -> element with the factor rho (one product by rho 2^D mod p)
+template <class E, int N>
+AMDMSM_DEV void re_from_words_rho(E& r, const uint32_t (&w)[N]) {
+    using P = typename re_info<E>::params;
+    constexpr int BL = rr_shape<P>::B * rr_shape<P>::L;
+    E t, c;
+    re_from_words<0>(t, w);
+    re_set_pow2<BL + rr_shape<P>::D>(c);
+    re_mul(r, t, c);
+}
+// p = 2 p, dbl-2009-l with a = 0 (2M + 5S), as jac_dbl (ec.cuh).  A point of order two (y == 0) doubles to infinity.
+template <class E>
+AMDMSM_DEV void jac_dbl_rr(JacRr<E>& p, bool& inf) {
+    if (inf) return;
+    if (re_maybe_zero<64>(p.y) && re_is_zero_exact(p.y)) {
+        inf = true;
+        return;
+    }
+    E a, b, c, d, e, f, t, yz;
+    re_sqr(a, p.x);               // A = X^2
+    re_sqr(b, p.y);               // B = Y^2
+    re_sqr(c, b);                 // C = B^2
+    re_mul(yz, p.y, p.z);
+    re_add(t, p.x, b);
+    re_norm(t, t);                // X + B, limbs back within the factor bound
+    re_sqr(d, t);
+    re_sub(d, d, a);
+    re_sub(d, d, c);
+    re_small_times(d, d, 2);      // D = 2((X + B)^2 - A - C)
+    re_small_times(e, a, 3);      // E = 3A
+    re_sqr(f, e);                 // F = E^2
+    re_small_times(t, d, 2);
+    re_sub(t, f, t);
+    re_norm(p.x, t);              // X3 = F - 2D
+    re_sub(t, d, p.x);
+    re_mul(f, e, t);              // E (D - X3)
+    re_small_times(c, c, 4);
+    re_small_times(c, c, 2);      // 8C
+    re_sub(t, f, c);
+    re_norm(p.y, t);              // Y3
+    re_small_times(p.z, yz, 2);   // Z3 = 2 Y Z
+}
+// acc += (px, py), an affine point already in reduced radix with the factor rho; madd-2007-bl with the special-case ladder
+// of G::mixed_add, as jac_madd (ec.cuh)
+template <class E>
+AMDMSM_DEV void jac_madd_rr(JacRr<E>& acc, bool& inf, const E& px, const E& py) {
+    using P = typename re_info<E>::params;
+    constexpr int BL = rr_shape<P>::B * rr_shape<P>::L;
+    if (inf) {
+        acc.x = px;
+        acc.y = py;
+        re_set_pow2<BL>(acc.z);   // one
+        inf = false;
+        return;
+    }
+    E z1z1, u2, s2, h, hh, i4, j, r, v, t;
+    re_sqr(z1z1, acc.z);
+    re_mul(u2, px, z1z1);
+    re_mul(s2, acc.z, z1z1);
+    re_mul(s2, py, s2);
+    re_sub(h, u2, acc.x);         // H
+    re_sub(r, s2, acc.y);
+    if (re_maybe_zero<64>(h) && re_is_zero_exact(h)) {
+        if (re_is_zero_exact(r)) {   // the same point
+            acc.x = px;
+            acc.y = py;
+            re_set_pow2<BL>(acc.z);
+            jac_dbl_rr(acc, inf);
+        } else {
+            inf = true;              // opposite points
+        }
+        return;
+    }
+    re_sqr(hh, h);                // HH
+    re_small_times(i4, hh, 4);    // I = 4 HH
+    re_mul(j, h, i4);             // J
+    re_small_times(r, r, 2);      // r = 2 (S2 - Y1)
+    re_mul(v, acc.x, i4);         // V
+    re_mul(t, acc.z, h);
+    re_small_times(acc.z, t, 2);  // Z3 = 2 Z1 H
+    re_sqr(t, r);
+    re_sub(t, t, j);
+    re_small_times(hh, v, 2);
+    re_sub(t, t, hh);
+    re_norm(acc.x, t);            // X3 = r^2 - J - 2V
+    re_mul(j, acc.y, j);          // Y1 J
+    re_sub(v, v, acc.x);
+    re_mul(v, r, v);              // r (V - X3)
+    re_small_times(j, j, 2);
+    re_sub(t, v, j);
+    re_norm(acc.y, t);            // Y3
+}
+// the point is infinity (flag, or Z == 0 exactly)
+template <class E>
+AMDMSM_DEV bool jac_is_inf_rr(const JacRr<E>& p, bool inf) {
+    return inf || re_is_zero_exact(p.z);
 }
 
 }  // namespace amdmsm

@@ -119,6 +119,58 @@ __global__ void __launch_bounds__(256) k_check2(const uint32_t* __restrict__ pts
     for (int j = 0; j < N; ++j) outrr[t * 4 * N + 3 * N + j] = w[j];
 }
 
+// Jacobian chains (the subgroup tests of the FFI decoder): doublings and mixed additions on reduced-radix limbs
+// (jac_dbl_rr / jac_madd_rr) against jac_dbl / jac_madd on 32-bit words, compared as affine points (equal points may be
+// doubled from different representatives) -- a double-and-add over a per-lane bit pattern, with the point itself and
+// its negative thrown in so that the equal / opposite branches run
+template <class P>
+__global__ void __launch_bounds__(256) k_check_jac(const uint32_t* __restrict__ pts, size_t npts, int len, uint32_t* out32,
+                                                   uint32_t* outrr) {
+    constexpr int N = P::N;
+    using F = Fp<P, true>;
+    using R = Rr<P>;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t idx = (i * 131) % npts;
+    uint32_t wx[N], wy[N];
+    for (int j = 0; j < N; ++j) { wx[j] = pts[idx * 2 * N + j]; wy[j] = pts[idx * 2 * N + N + j]; }
+    Aff<F> p, n;
+    for (int j = 0; j < N; ++j) { p.x.v[j] = wx[j]; p.y.v[j] = wy[j]; }
+    n = p;
+    fp_neg(n.y, n.y);
+    R px, py, ny;
+    re_from_words_rho(px, wx);
+    re_from_words_rho(py, wy);
+    re_neg(ny, py);
+    re_norm(ny, ny);
+    Jac<F> a;
+    jac_set_inf(a);
+    JacRr<R> b;
+    rr_zero(b.x); rr_zero(b.y); rr_zero(b.z);
+    bool inf = true;
+    uint32_t bits = (uint32_t)(i * 2654435761u) | 1u;
+    for (int k = 0; k < len; ++k) {
+        jac_dbl(a, a);
+        jac_dbl_rr(b, inf);
+        const uint32_t sel = (bits >> (k % 29)) & 3u;
+        if (sel == 1u || (i % 8 == 1 && k < 2)) { jac_madd(a, p); jac_madd_rr(b, inf, px, py); }
+        if (sel == 2u || (i % 8 == 2 && k == 1)) { jac_madd(a, n); jac_madd_rr(b, inf, px, ny); }
+    }
+    // 32-bit side: affine (0, 0) for infinity
+    Aff<F> ra;
+    if (jac_is_inf(a)) { fp_set_zero(ra.x); fp_set_zero(ra.y); } else jac_to_aff(ra, a);
+    for (int j = 0; j < N; ++j) { out32[i * 2 * N + j] = ra.x.v[j]; out32[i * 2 * N + N + j] = ra.y.v[j]; }
+    Jac<F> e;
+    Aff<F> rb;
+    if (jac_is_inf_rr(b, inf)) { fp_set_zero(rb.x); fp_set_zero(rb.y); }
+    else {
+        rr_export_component<P, 0>(e.x.v, b.x);
+        rr_export_component<P, 0>(e.y.v, b.y);
+        rr_export_component<P, 0>(e.z.v, b.z);
+        jac_to_aff(rb, e);
+    }
+    for (int j = 0; j < N; ++j) { outrr[i * 2 * N + j] = rb.x.v[j]; outrr[i * 2 * N + N + j] = rb.y.v[j]; }
+}
+
 template <class P, int WAVES>
 __global__ void __launch_bounds__(256, WAVES) k_time32(const uint32_t* __restrict__ pts, size_t npts, int len, uint32_t* out) {
     constexpr int N = P::N;
@@ -236,6 +288,20 @@ int run(const char* name) {
             }
         }
         printf("%s%s: len %2d: %d mismatches of %zu lanes\n", name, pass ? " (edge operands)" : "", len, mism, lanes);
+        bad += mism;
+    }
+    for (int len : {1, 2, 5, 40}) {
+        hipLaunchKernelGGL(k_check_jac<P>, dim3(lanes / 256), dim3(256), 0, 0, dp, npts, len, o32, orr);
+        std::vector<uint32_t> a(lanes * 2 * N), b(lanes * 2 * N);
+        hipMemcpy(a.data(), o32, a.size() * 4, hipMemcpyDeviceToHost);
+        hipMemcpy(b.data(), orr, b.size() * 4, hipMemcpyDeviceToHost);
+        int mism = 0;
+        for (size_t i = 0; i < lanes; ++i) {
+            bool eq = true;
+            for (int j = 0; j < 2 * N; ++j) eq &= a[i * 2 * N + j] == b[i * 2 * N + j];
+            if (!eq && mism++ < 3) printf("  Jacobian mismatch lane %zu len %d\n", i, len);
+        }
+        printf("%s, Jacobian chains: len %2d: %d mismatches of %zu lanes\n", name, len, mism, lanes);
         bad += mism;
     }
     if constexpr (NR2 != 0) {
