@@ -1,4 +1,6 @@
-// Reduced-radix prime-field arithmetic for the bucket-accumulation loop (k_accumulate).
+// Reduced-radix prime-field arithmetic for the bucket-accumulation loop (k_accumulate), the fixed-base
+// exponentiation (k_fb_exp_rr) and the subgroup tests of the FFI decoder -- the kernels that run at the
+// multiply-issue rate.
 //
 // Same field as fp.cuh -- libff's Fp_model<n, modulus> (fp.hpp:38-160, mul_reduce fp.tcc:50-228) --
 // but held as L signed limbs of B = 28 / 29 bits instead of N full 32-bit words:
@@ -14,9 +16,12 @@
 //   * the Montgomery radix is rho = 2^(B L) >= 2^(32 N + 5): p / rho <= 2^-7, so a product of
 //     operands bounded by A p and A' p lies in (-e p, (1 + e) p) with e = A A' p / rho -- values
 //     contract, nothing in the loop ever needs a conditional subtraction.
-// Nothing here is stored or compared in this form outside k_accumulate: k_rr_export turns the
-// accumulators back into canonical 32-bit Montgomery residues (R = 2^(32N), fp.cuh) before any
-// other kernel reads them.
+// Nothing is kept in this form between kernels: k_rr_export turns k_accumulate's records back into
+// canonical 32-bit Montgomery residues (R = 2^(32N), fp.cuh) before any other kernel reads them,
+// the other users convert in registers.  Contents: limbs and constants, multiply chains, products /
+// squaring / linear operations, conversions and exact residue tests, the element interface re_* (Fq per
+// lane, Fq2 over a lane pair), the XYZZ mixed addition of the bucket loop, export, Jacobian doubling /
+// mixed addition.
 #pragma once
 #include "fp.cuh"
 
