@@ -2368,15 +2368,23 @@ AMDMSM_DEV bool endo_subgroup_check_rr(const uint32_t (&wx)[FQ::N], const uint32
     re_from_words_rho(beta, G::ENDO_BETA);
     re_mul(sx, px, beta);   // sigma(x, y) = (beta x, y)
     JacRr<R> t;
+    rr_zero(t.x); rr_zero(t.y); rr_zero(t.z);
     bool inf = true;
-    for (int i = 4 * 32 - 1; i >= 0; --i) {   // [c1] sigma(P), most significant bit first (curve_utils.tcc:14-32)
+    // one doubling and one addition in the code (each inlined copy costs registers: five sites put the kernel at one wave
+    // per SIMD): the closing "+ P" is step -1 of the same loop
+#pragma nounroll
+    for (int i = 4 * 32 - 1; i >= -1; --i) {   // [c1] sigma(P), most significant bit first (curve_utils.tcc:14-32), then + P
         uint32_t w = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) w = ((i >> 5) == j) ? G::ENDO_C1[j] : w;
-        jac_dbl_rr(t, inf);
-        if ((w >> (i & 31)) & 1u) jac_madd_rr(t, inf, sx, py);
+        if (i >= 0) jac_dbl_rr(t, inf);
+        if (i < 0 || ((w >> (i & 31)) & 1u)) {
+            R ax;
+#pragma unroll
+            for (int k = 0; k < R::L; ++k) ax.v[k] = i < 0 ? px.v[k] : sx.v[k];
+            jac_madd_rr(t, inf, ax, py);
+        }
     }
-    jac_madd_rr(t, inf, px, py);
     return jac_is_inf_rr(t, inf);
 }
 template <class G>
@@ -2390,15 +2398,29 @@ AMDMSM_DEV bool lattice_subgroup_check_rr(const uint32_t (&wx)[FQ::N], const uin
     re_neg(ny, py);
     re_norm(ny, ny);
     JacRr<R> t;
+    rr_zero(t.x); rr_zero(t.y); rr_zero(t.z);
     bool inf = true;
+    // one doubling and one addition in the code: the digits of a (part 0) and b (part 1) take turns in an inner loop
+    // (non-adjacent forms: at most one of +-P and one of +-phi(P) per bit)
+#pragma nounroll
     for (int i = GLV::SUB_BITS - 1; i >= 0; --i) {
         jac_dbl_rr(t, inf);
         const int wd = i >> 5;
         const uint32_t m = 1u << (i & 31);
-        if (GLV::SUB_A_POS[wd] & m) jac_madd_rr(t, inf, p1x, py);
-        if (GLV::SUB_A_NEG[wd] & m) jac_madd_rr(t, inf, p1x, ny);
-        if (GLV::SUB_B_POS[wd] & m) jac_madd_rr(t, inf, p2x, py);
-        if (GLV::SUB_B_NEG[wd] & m) jac_madd_rr(t, inf, p2x, ny);
+#pragma nounroll
+        for (int part = 0; part < 2; ++part) {
+            const bool pos = ((part ? GLV::SUB_B_POS[wd] : GLV::SUB_A_POS[wd]) & m) != 0;
+            const bool neg = ((part ? GLV::SUB_B_NEG[wd] : GLV::SUB_A_NEG[wd]) & m) != 0;
+            if (pos || neg) {
+                R ax, ay;
+#pragma unroll
+                for (int k = 0; k < R::L; ++k) {
+                    ax.v[k] = part ? p2x.v[k] : p1x.v[k];
+                    ay.v[k] = pos ? py.v[k] : ny.v[k];
+                }
+                jac_madd_rr(t, inf, ax, ay);
+            }
+        }
     }
     return jac_is_inf_rr(t, inf);
 }
@@ -2446,7 +2468,7 @@ AMDMSM_DEV bool in_safe_subgroup(const Aff<E>& a) {
 }
 
 // status bits: 1 = coordinate out of range, 2 = not on the curve, 4 = not in the safe subgroup
-__global__ void __launch_bounds__(TPB) k_ffi_decode_points(const uint32_t* __restrict__ src, size_t n,
+__global__ void __launch_bounds__(TPB, (AMDMSM_ACC_RR && GP::DEG == 1 && FQ::N <= 12) ? 2 : 1) k_ffi_decode_points(const uint32_t* __restrict__ src, size_t n,
                                                            uint32_t* __restrict__ dst, uint32_t* __restrict__ status) {
     const size_t i = gtid();
     if (i >= n) return;
