@@ -234,8 +234,10 @@ double plan_cost(const group_vtable *vt, size_t n, int c, bool glv) {
     const double wide = vt->fq_words >= 24 ? 2.2 : ((vt->fq_words > 8 || vt->el_words > vt->fq_words) ? 1.5 : 1.0);
     // (the wider fields hide the second base load behind their longer additions: same rate either way)
     // (round 3: with the cheaper reduction the split still wins a little above 2^22 points for the 8-limb field -- 2^22:
-    // c = 19, 7 windows 7.16 ms against 7.3-7.5 plain; 2^23: 13.5 against 13.1 -- so its entries are priced level up to 5 M points)
-    const double entry = !glv ? 1.0 : (n < ((size_t)1 << 22) ? 1.0 : (wide > 1.0 ? 1.02 : (n < ((size_t)5 << 20) ? 1.0 : 1.08)));
+    // c = 19, 7 windows 7.16 ms against 7.3-7.5 plain; 2^23: 13.5 against 13.1 -- so its entries are priced level up to 5 M points;
+    // with the reduced-radix accumulation: 2^23 12.0 either way, 2^24 21.8 (split, c = 19) against 22.8, 2^25 41.6 against 40.4,
+    // 2^26 77.9 (c = 22) against 75.3 -- level up to 20 M points)
+    const double entry = !glv ? 1.0 : (n < ((size_t)1 << 22) ? 1.0 : (wide > 1.0 ? 1.02 : (n < ((size_t)20 << 20) ? 1.0 : 1.08)));
     const bool large = n >= ((size_t)1 << 23);
     // windows that can hold a nonzero digit: with W * c well above the scalar length the top
     // window sees neither a scalar bit nor the carry (c = 17: 15 of 16 windows for a 254-bit
