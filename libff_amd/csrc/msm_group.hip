@@ -11,8 +11,9 @@
 //                fallback for c > 22)
 //   k_accumulate one lane per S consecutive entries of a window's sorted list (segmented sum
 //                by bucket, fixed work per lane): mixed additions
-//                (multi_exp_add_element_to_bucket_with_signed_digit, multiexp.tcc:45-81);
-//                k_accumulate_fixup closes the buckets that span lanes
+//                (multi_exp_add_element_to_bucket_with_signed_digit, multiexp.tcc:45-81) on
+//                reduced-radix limbs (rr.cuh); k_rr_export rewrites the accumulator records as
+//                canonical 32-bit words; k_accumulate_fixup closes the buckets that span lanes
 //   k_reduce_segments / k_sum_butterfly
 //                sum_b (b+1) * B_b (multiexp_accumulate_buckets, multiexp.tcc:90-125)
 //                as L-bucket running sums + a small scalar multiple per segment, folded
