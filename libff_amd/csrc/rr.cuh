@@ -548,16 +548,76 @@ struct XyzzRr {
     E x, y, zz, zzz;
 };
 
-// the first point of a bucket: (x 2^D, y 2^D, 1, 1) in the factors above (values below 2^D p)
+// The first point of a bucket is x 2^D as an integer: up to 2^D p.  Products contract values by p / rho per factor, an Fq2
+// product sums two of them and the complex squaring multiplies a sum by a difference: where 2^(D + 2) p / rho is not well
+// below one (alt_bn128: D = 5 against 7 spare bits) a worst-case alignment of signs could let the bounds of the following
+// additions grow instead of shrink (tests/test_rr_bounds.py walks them).  For those Fq2 fields the first point is reduced:
+// q = floor(2^D x / p) estimated from the top word (never too large, at most one too small), q p taken from a table of
+// 2^D + 1 multiples, x 2^D - q p in [0, 2p) with limbs in (-2^B, 2^B).
+template <class P>
+struct rr_qp_tab {
+    uint32_t v[(1 << rr_shape<P>::D) + 1][rr_shape<P>::L];
+};
+template <class P>
+constexpr rr_qp_tab<P> rr_make_qp() {
+    constexpr int L = rr_shape<P>::L;
+    constexpr int B = rr_shape<P>::B;
+    rr_qp_tab<P> t{};
+    for (int q = 1; q <= (1 << rr_shape<P>::D); ++q) {
+        uint32_t carry = 0;
+        for (int i = 0; i < L; ++i) {
+            const uint32_t sum = t.v[q - 1][i] + rr_tab<P>::PL.v[i] + carry;
+            t.v[q][i] = i + 1 < L ? (sum & rr_shape<P>::M) : sum;
+            carry = i + 1 < L ? (sum >> B) : 0u;
+        }
+    }
+    return t;
+}
+template <class P>
+__device__ const rr_qp_tab<P> rr_qp = rr_make_qp<P>();
+template <class E>
+constexpr bool rr_first_needs_reduction() {
+    using P = typename re_info<E>::params;
+    return re_info<E>::PAIR && rr_shape<P>::D + 2 >= rr_shape<P>::B * rr_shape<P>::L - P::BITS;
+}
+// limbs of (w 2^D - q p), w < p
+template <class P>
+AMDMSM_DEV void rr_first_reduced(Rr<P>& r, const uint32_t (&w)[P::N]) {
+    constexpr int D = rr_shape<P>::D;
+    constexpr uint32_t PT1 = P::P[P::N - 1] + 1u;   // above p / 2^(32 (N - 1))
+    // largest shift with 2^(32 + SH + D) / PT1 below 2^32
+    constexpr int SH = [] {
+        int sh = 0;
+        while (sh < 31 && ((1ull << (32 + sh + 1 + D)) / PT1) < (1ull << 32)) ++sh;
+        return sh;
+    }();
+    constexpr uint32_t RECIP = (uint32_t)((1ull << (32 + SH + D)) / PT1);
+    const uint32_t q = __umulhi(w[P::N - 1], RECIP) >> SH;   // <= floor(2^D w / p), at most one below it
+    rr_from_words<P, D>(r, w);
+#pragma unroll
+    for (int i = 0; i < Rr<P>::L; ++i) r.v[i] -= (int32_t)rr_qp<P>.v[q][i];
+}
+
+// a coordinate with the factor rho from its words (factor 2^(32N)): the words times 2^D, reduced where that is needed
+template <class E, int N>
+AMDMSM_DEV void re_first_coord(E& r, const uint32_t (&w)[N]) {
+    using P = typename re_info<E>::params;
+    if constexpr (rr_first_needs_reduction<E>()) rr_first_reduced<P>(r.h, w);
+    else re_from_words<rr_shape<P>::D>(r, w);
+}
+// the first point of a bucket: (x 2^D, y 2^D, 1, 1) in the factors above (values below 2^D p; below 2 p where reduced)
 template <class E, int N>
 AMDMSM_DEV void xyzz_rr_first(XyzzRr<E>& acc, const uint32_t (&wx)[N], const uint32_t (&wy)[N], bool neg) {
     using P = typename re_info<E>::params;
     constexpr int D = rr_shape<P>::D;
     constexpr int BL = rr_shape<P>::B * rr_shape<P>::L;
-    re_from_words<D>(acc.x, wx);
-    re_from_words<D>(acc.y, wy);
+    re_first_coord(acc.x, wx);
+    re_first_coord(acc.y, wy);
     re_cneg(acc.y, acc.y, neg);
-    re_norm(acc.y, acc.y);   // limbs of -y back into [-1, 2^B): R = S2 - Y1 then stays within B bits (+ sign) like every other factor
+    // limbs of -y (and of a reduced x) back into [-1, 2^B]: P = U2 - X1 and R = S2 - Y1 then stay within B bits (+ sign)
+    // like every other factor
+    re_norm(acc.y, acc.y);
+    if constexpr (rr_first_needs_reduction<E>()) re_norm(acc.x, acc.x);
     re_set_pow2<BL + D>(acc.zz);
     acc.zzz = acc.zz;
 }
@@ -605,8 +665,8 @@ AMDMSM_DEV bool xyzz_rr_same_x(XyzzRr<E>& acc, bool& inf, const E& pp, const E& 
     }
     // x, y with the factor rho (values below 2^D p)
     E x, y, v, w, s, m, t, c;
-    re_from_words<D>(x, wx);
-    re_from_words<D>(y, wy);
+    re_first_coord(x, wx);
+    re_first_coord(y, wy);
     re_cneg(y, y, neg);
     re_mul(t, y, y);
     re_small_times(v, t, 4);    // V = (2Y)^2
