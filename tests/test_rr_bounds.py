@@ -259,6 +259,7 @@ def test_bucket_loop_bounds_fq(name):
         for _ in range(4):
             assert acc["x"].val <= 2 ** ch.s.D and acc["y"].val <= 2 ** ch.s.D, acc
             acc = madd(ch, acc)
+    # the top limb keeps 3 (29-bit limbs) or 4 spare bits: every value stays below 2^(32 - B) rho / p in magnitude
 
 
 @pytest.mark.parametrize("name", list(FQ2_NR))
@@ -266,6 +267,11 @@ def test_bucket_loop_bounds_fq2(name):
     ch = Checker(Shape(name))
     run_sequences(ch, fq2_nr=FQ2_NR[name])
     assert ch.worst_column < 2 ** 63
+    for start in (first_point(ch, FQ2_NR[name]), doubling_path(ch, FQ2_NR[name])):   # export: |x|, |y| below 2^D p in every state
+        acc = start
+        for _ in range(4):
+            assert acc["x"].val <= 2 ** ch.s.D and acc["y"].val <= 2 ** ch.s.D, acc
+            acc = madd(ch, acc, fq2_nr=FQ2_NR[name])
 
 
 @pytest.mark.parametrize("name", ["bls12_377", "bls12_381", "bw6_761"])
