@@ -592,7 +592,8 @@ AMDMSM_DEV void rr_first_reduced(Rr<P>& r, const uint32_t (&w)[P::N]) {
         return sh;
     }();
     constexpr uint32_t RECIP = (uint32_t)((1ull << (32 + SH + D)) / PT1);
-    const uint32_t q = __umulhi(w[P::N - 1], RECIP) >> SH;   // <= floor(2^D w / p), at most one below it
+    uint32_t q = __umulhi(w[P::N - 1], RECIP) >> SH;   // <= floor(2^D w / p), at most one below it
+    q = q < (1u << D) ? q : (1u << D);                  // (w < p by contract; the table is never left whatever the words hold)
     rr_from_words<P, D>(r, w);
 #pragma unroll
     for (int i = 0; i < Rr<P>::L; ++i) r.v[i] -= (int32_t)rr_qp<P>.v[q][i];
