@@ -1987,6 +1987,50 @@ __global__ void __launch_bounds__(TPB) k_export_affine(const uint32_t* __restric
 // writes to disk for multi_exp_stream_with_precompute): table[i*D + j] = [2^(j*c)] P_i, affine.
 // One lane walks one base through (D-1)*c doublings; (X, Y) are parked in the table slots and
 // (Z, prefix product of the Z's) in tmp, then one inversion per lane turns all D entries affine.
+#if AMDMSM_ACC_RR
+// The doubling chain of one table row on reduced-radix limbs (groups with coordinates in Fq): (D - 1) c doublings with the
+// squarings the 32-bit words cannot afford, (X, Y, Z) exported to canonical words every c doublings for the shared inversion
+// that follows.  Returns false where it does not apply (the caller then runs the 32-bit chain).
+template <class G, class A, class EL>   // G = GP, A = Aff<E>, EL = E: template parameters keep the Fq2 groups from instantiating the body
+AMDMSM_DEV bool precompute_chain_rr(const A& a, int c, int D, uint32_t* row, uint32_t* trow, EL& acc, int& last) {
+    if constexpr (G::DEG == 1) {
+        using FQL = typename G::fq;
+        using R = Rr<FQL>;
+        uint32_t wx[FQL::N], wy[FQL::N];
+        uint32_t any = 0;
+#pragma unroll
+        for (int j = 0; j < FQL::N; ++j) {
+            wx[j] = a.x.v[j];
+            wy[j] = a.y.v[j];
+            any |= wx[j] | wy[j];
+        }
+        JacRr<R> cur;
+        re_from_words_rho(cur.x, wx);
+        re_from_words_rho(cur.y, wy);
+        re_set_pow2<rr_shape<FQL>::B * rr_shape<FQL>::L>(cur.z);   // one
+        bool inf = any == 0;
+        for (int j = 1; j < D; ++j) {
+#pragma nounroll
+            for (int k = 0; k < c; ++k) jac_dbl_rr(cur, inf);
+            if (jac_is_inf_rr(cur, inf)) break;
+            EL x, y, z;
+            rr_export_component<FQL, 0>(x.v, cur.x);
+            rr_export_component<FQL, 0>(y.v, cur.y);
+            rr_export_component<FQL, 0>(z.v, cur.z);
+            el_store(row + (size_t)j * AFFW, x);
+            el_store(row + (size_t)j * AFFW + EW, y);
+            el_store(trow + (size_t)j * AFFW, z);
+            el_store(trow + (size_t)j * AFFW + EW, acc);
+            el_mul(acc, acc, z);
+            last = j;
+        }
+        return true;
+    } else {
+        return false;
+    }
+}
+#endif
+
 __global__ void __launch_bounds__(TPB) k_precompute_table(const uint32_t* __restrict__ bases, size_t n, int c, int D,
                                                           uint32_t* __restrict__ tmp, uint32_t* __restrict__ table) {
     const size_t i = gtid();
@@ -1996,20 +2040,26 @@ __global__ void __launch_bounds__(TPB) k_precompute_table(const uint32_t* __rest
     uint32_t* row = table + i * (size_t)D * AFFW;
     uint32_t* trow = tmp + i * (size_t)D * AFFW;   // per entry: Z, prefix
     store_aff(row, a);
-    Jac<E> cur;
-    jac_from_aff(cur, a);
     E acc;
     el_one(acc);
     int last = 0;   // entries 1 .. last are finite (an infinite base or a point of even order stops early)
-    for (int j = 1; j < D; ++j) {
-        for (int k = 0; k < c; ++k) jac_dbl(cur, cur);
-        if (jac_is_inf(cur)) break;
-        el_store(row + (size_t)j * AFFW, cur.x);
-        el_store(row + (size_t)j * AFFW + EW, cur.y);
-        el_store(trow + (size_t)j * AFFW, cur.z);
-        el_store(trow + (size_t)j * AFFW + EW, acc);
-        el_mul(acc, acc, cur.z);
-        last = j;
+#if AMDMSM_ACC_RR
+    if (precompute_chain_rr<GP>(a, c, D, row, trow, acc, last)) {
+    } else
+#endif
+    {
+        Jac<E> cur;
+        jac_from_aff(cur, a);
+        for (int j = 1; j < D; ++j) {
+            for (int k = 0; k < c; ++k) jac_dbl(cur, cur);
+            if (jac_is_inf(cur)) break;
+            el_store(row + (size_t)j * AFFW, cur.x);
+            el_store(row + (size_t)j * AFFW + EW, cur.y);
+            el_store(trow + (size_t)j * AFFW, cur.z);
+            el_store(trow + (size_t)j * AFFW + EW, acc);
+            el_mul(acc, acc, cur.z);
+            last = j;
+        }
     }
     E inv;
     el_inv(inv, acc);

@@ -35,8 +35,15 @@ class Shape:
 class El:
     """worst-case ranges of one element: [lo, hi] of limbs 0..L-2, [tlo, thi] of the top limb, |value| in units of p"""
 
-    def __init__(self, lo, hi, tlo, thi, val):
-        self.lo, self.hi, self.tlo, self.thi, self.val = lo, hi, tlo, thi, val
+    def __init__(self, lo, hi, tlo, thi, val, vlo=None, vhi=None):
+        self.lo, self.hi, self.tlo, self.thi = lo, hi, tlo, thi
+        # the value as an interval [vlo, vhi] in units of p (a magnitude `val` alone means [-val, val])
+        self.vlo = -val if vlo is None else vlo
+        self.vhi = val if vhi is None else vhi
+
+    @property
+    def val(self):
+        return max(abs(self.vlo), abs(self.vhi))
 
     @property
     def mag(self):
@@ -51,11 +58,11 @@ class El:
         return max(abs(self.tlo), abs(self.thi))
 
     def __repr__(self):
-        return f"El(limbs [{self.lo}, {self.hi}], top [{self.tlo}, {self.thi}], val {self.val:.1f} p)"
+        return f"El(limbs [{self.lo}, {self.hi}], top [{self.tlo}, {self.thi}], value [{self.vlo:.1f}, {self.vhi:.1f}] p)"
 
 
 def hull(a, b):
-    return El(min(a.lo, b.lo), max(a.hi, b.hi), min(a.tlo, b.tlo), max(a.thi, b.thi), max(a.val, b.val))
+    return El(min(a.lo, b.lo), max(a.hi, b.hi), min(a.tlo, b.tlo), max(a.thi, b.thi), 0, min(a.vlo, b.vlo), max(a.vhi, b.vhi))
 
 
 class Checker:
@@ -82,20 +89,24 @@ class Checker:
             la, lb, ta, tb = a.limb_mag, b.limb_mag, a.top_mag, b.top_mag
             return max(s.L * la * lb, (s.L - 2) * la * lb + ta * lb + la * tb, ta * tb + (s.L - 2) * la * lb)
 
+        slo = shi = 0.0   # the sum of products as an interval, in units of p^2
         for a, b in pairs:
             col += column(a, b)
-            val += a.val * b.val
-        for a in squares:   # every cross product once against the doubled limbs: the same sum as a * a
+            c = (a.vlo * b.vlo, a.vlo * b.vhi, a.vhi * b.vlo, a.vhi * b.vhi)
+            slo += min(c)
+            shi += max(c)
+        for a in squares:   # every cross product once against the doubled limbs: the same sum as a * a, never negative
             assert 2 * a.mag < 2 ** 31
             col += column(a, a)
-            val += a.val * a.val
+            slo += 0.0 if a.vlo <= 0.0 <= a.vhi else min(a.vlo * a.vlo, a.vhi * a.vhi)
+            shi += max(a.vlo * a.vlo, a.vhi * a.vhi)
         col += s.L * (2 ** s.B) ** 2           # m * p
         col += 2 ** (64 - s.B)                 # carry in from the column below
         self.worst_column = max(self.worst_column, col)
         assert col < 2 ** 63, f"column sum 2^{math.log2(col):.2f} overflows int64: {pairs} {squares}"
-        out_val = val * s.ratio + 1.0          # result in (S / rho, S / rho + p)
-        t = self._top_of(out_val)
-        return El(0, 2 ** s.B - 1, -t, t, out_val)
+        vlo, vhi = slo * s.ratio, shi * s.ratio + 1.0   # result in (S / rho, S / rho + p)
+        t = self._top_of(max(abs(vlo), abs(vhi)))
+        return El(0, 2 ** s.B - 1, -t if vlo < 0 else 0, t, 0, vlo, vhi)
 
     def mul(self, a, b):
         return self.product([(a, b)])
@@ -109,13 +120,15 @@ class Checker:
         hi = sum(k * (t.hi if k > 0 else t.lo) for k, t in terms)
         tlo = sum(k * (t.tlo if k > 0 else t.thi) for k, t in terms)
         thi = sum(k * (t.thi if k > 0 else t.tlo) for k, t in terms)
-        return self._i32(El(lo, hi, tlo, thi, sum(abs(k) * t.val for k, t in terms)))
+        vlo = sum(k * (t.vlo if k > 0 else t.vhi) for k, t in terms)
+        vhi = sum(k * (t.vhi if k > 0 else t.vlo) for k, t in terms)
+        return self._i32(El(lo, hi, tlo, thi, 0, vlo, vhi))
 
     def norm(self, a):
         """rr_norm: limb' = (limb & M) + (carry of the limb below); top' = top + carry"""
         self._i32(a)
         clo, chi = a.lo >> self.s.B, a.hi >> self.s.B   # arithmetic shifts
-        return self._i32(El(min(0, clo), 2 ** self.s.B - 1 + max(0, chi), a.tlo + clo, a.thi + chi, a.val))
+        return self._i32(El(min(0, clo), 2 ** self.s.B - 1 + max(0, chi), a.tlo + clo, a.thi + chi, 0, a.vlo, a.vhi))
 
     def small_times(self, a, k):
         return self.norm(self.lin([(k, a)]))
@@ -129,11 +142,11 @@ def canonical(ch, negated=False):
     """a base coordinate straight from its words (negated: after the conditional limb-wise negation)"""
     s = ch.s
     t = ch._top_of(1.0)
-    return El(-(2 ** s.B - 1), 0, -t, 0, 1.0) if negated else El(0, 2 ** s.B - 1, 0, t, 1.0)
+    return El(-(2 ** s.B - 1), 0, -t, 0, 0, -1.0, 0.0) if negated else El(0, 2 ** s.B - 1, 0, t, 0, 0.0, 1.0)
 
 
 def one_el(ch):
-    return El(0, 2 ** ch.s.B - 1, 0, ch._top_of(1.0), 1.0)
+    return El(0, 2 ** ch.s.B - 1, 0, ch._top_of(1.0), 0, 0.0, 1.0)
 
 
 def first_point(ch, fq2_nr=0):
@@ -142,10 +155,11 @@ def first_point(ch, fq2_nr=0):
     s = ch.s
     if first_needs_reduction(s, fq2_nr):
         t = ch._top_of(2.0)
-        x = ch.norm(El(-(2 ** s.B - 1), 2 ** s.B - 1, -t, t, 2.0))
-        return dict(x=x, y=x, zz=one_el(ch), zzz=one_el(ch))
+        x = ch.norm(El(-(2 ** s.B - 1), 2 ** s.B - 1, -t, t, 0, 0.0, 2.0))
+        y = ch.norm(El(-(2 ** s.B - 1), 2 ** s.B - 1, -t, t, 0, -2.0, 2.0))
+        return dict(x=x, y=y, zz=one_el(ch), zzz=one_el(ch))
     t = ch._top_of(float(2 ** s.D))
-    x = El(0, 2 ** s.B - 1, 0, t, float(2 ** s.D))
+    x = El(0, 2 ** s.B - 1, 0, t, 0, 0.0, float(2 ** s.D))
     y = ch.norm(El(-(2 ** s.B - 1), 2 ** s.B - 1, -t, t, float(2 ** s.D)))
     return dict(x=x, y=y, zz=one_el(ch), zzz=one_el(ch))
 
@@ -218,7 +232,7 @@ def doubling_path(ch, fq2_nr=0):
     mul, sqr, mul_sub_mul = ops(ch, fq2_nr)
     fp = first_point(ch, fq2_nr)
     x = fp["x"]
-    y = El(-x.hi, x.hi, -x.thi, x.thi, x.val)   # conditional limb-wise negation only
+    y = El(-x.hi, x.hi, -x.thi, x.thi, x.val)   # conditional limb-wise negation only: either sign
     v = ch.small_times(mul(y, y), 4)
     w = ch.small_times(mul(y, v), 2)
     sv = mul(x, v)
@@ -274,7 +288,7 @@ def test_bucket_loop_bounds_fq2(name):
             acc = madd(ch, acc, fq2_nr=FQ2_NR[name])
 
 
-@pytest.mark.parametrize("name", ["bls12_377", "bls12_381", "bw6_761"])
+@pytest.mark.parametrize("name", ["alt_bn128", "bls12_377", "bls12_381", "bw6_761"])
 def test_jacobian_chain_bounds(name):
     """jac_dbl_rr / jac_madd_rr (the decoder's subgroup tests): a point and its images under repeated steps"""
     ch = Checker(Shape(name))
@@ -320,8 +334,14 @@ def test_jacobian_chain_bounds(name):
         return x3, ch.norm(ch.lin([(1, g), (-1, ch.small_times(y1j, 2))])), z3
 
     p = (px, py, one)
-    for step in range(12):   # doublings with an addition behind every second one
+    for step in range(12):   # doublings with an addition behind every second one (the decoder's chains)
         p = dbl(p)
         if step % 2:
             p = madd_j(p)
+    p = (px, py, one)
+    for step in range(16):   # doublings only (k_precompute_table's rows)
+        p = dbl(p)
+    p = (px, py, one)
+    for step in range(8):    # an addition behind every doubling
+        p = madd_j(dbl(p))
     assert ch.worst_column < 2 ** 63
