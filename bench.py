@@ -102,6 +102,7 @@ def parse_args():
                          "on an HBM-resident table of [2^(jc)]P) with this window size; 0 disables")
     ap.add_argument("--no-next-rows", action="store_true",
                     help="N = 1: skip the batch_exp / multi_exp_stream / FFI legs (SURVEY.md section 8(f) rows)")
+    ap.add_argument("--no-r32", action="store_true", help="N = 1: skip the leg with the reference profiler's 32 repeated bases")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="N = 1: skip the configs[2] / configs[4] legs (bls12_377 G1 2^22; bw6_761 G1 + bls12_377 G2 at 2^21 and 2^24)")
     ap.add_argument("--config4-log2n", type=int, default=24, help="N > 1: total points of the configs[4] leg; 0 disables")
@@ -379,6 +380,11 @@ def other_config_legs(args, tm, dev, device_index):
         return b, s, n
 
     eng = libff_amd.Engine(device_index)
+    for lg in (23, 24, 25):   # configs[3]: what one rank of the 8 / 4 / 2-GPU run does
+        b, s, n = alone(eng, "alt_bn128", 1, lg, 0, f"shard_alt_bn128_g1_2p{lg}",
+                        f"BASELINE configs[3], per-rank shard alone: alt_bn128 G1 MSM, 2^{lg} points (2^26 over {1 << (26 - lg)} GPUs)")
+        del b, s
+        torch.cuda.empty_cache()
     b, s, n = alone(eng, "bls12_377", 1, 22, 0, "config2_bls12_377_g1_2p22",
                     "BASELINE configs[2]: bls12_377 G1 MSM (384-bit field), 2^22 points, 1 GPU")
     del b, s
@@ -525,6 +531,24 @@ def single_gpu(args, tm, eng, dev, curve, group):
                                      "overlaps the bulk kernels of the next; `value` stays the one-at-a-time figure"}
         msm = ShardedMsm(eng, curve, group, depth=1)
 
+    # ---- the reference profiler's own input shape: 32 distinct points repeated (profile_multiexp.cpp:14-15, 24-50) ----
+    if not args.no_legs and not args.no_r32:
+        first = torch.randint(0, 1 << 62, (32,), generator=torch.Generator().manual_seed(32)).tolist()
+        p32 = torch.empty((32, sz["affine_bytes"] // 8), dtype=torch.int64, device=dev)
+        for j, f in enumerate(first):   # P_j = (f_j + 1) G: 32 unrelated multiples of the generator
+            eng.gen_bases_seq_device(curve, group, f, 1, p32[j].data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        bases_r32 = p32.repeat(n // 32, 1).contiguous()
+        er, phr = timed_msm(tm, eng, msm, bases_r32, scalars, n, args.steps, args.warmup, args.window_bits)
+        acc_r = float(np.mean([p["accumulate_ms"] for p in phr]))
+        legs["r32_bases"] = {
+            "workload": f"{args.curve} G{group} MSM, 2^{log2n} points, bases = 32 distinct points repeated (the reference "
+                        "profiler's own input shape, profile_multiexp.cpp:14-15,24-50): equal and opposite points meet in "
+                        "the buckets all the time", "steps": args.steps, "value": n * args.steps / er, "unit": "scalar-muls/s",
+            "ms_per_step": er / args.steps * 1e3, "phases_ms": mean_phases(phr),
+            "roofline": roofline_of(args.curve, curve, group, n, plan, acc_r, 0)}
+        del bases_r32, p32
+
     # ---- k MSMs handed over as ONE batch (amdmsm_msm_device_batch): the tails of all of them run as one set of kernels ----
     if not args.no_legs and args.batch > 1:
         kb = args.batch
@@ -653,6 +677,50 @@ def single_gpu(args, tm, eng, dev, curve, group):
         legs.update(other_config_legs(args, tm, dev, eng.device))
 
     roof = roofline_of(args.curve, curve, group, n, plan, acc, log2n)
+    # The driver's record keeps scalar keys of `config` / `roofline` only (nested objects are dropped): the other half of
+    # the metric (2^26), the phase times and the other BASELINE configurations are repeated here as scalars.
+    mp = mean_phases(phases)
+    flat = {"sort_ms": mp.get("scatter_ms"), "accumulate_ms": mp.get("accumulate_ms"), "reduce_ms": mp.get("reduce_ms"),
+            "final_ms": mp.get("final_ms"), "device_total_ms": mp.get("total_ms"), "mac_issue_frac": roof["mac_issue"]["frac"]}
+    roof["mac_issue_frac"] = roof["mac_issue"]["frac"]
+    xl = legs.get(f"points_2p{args.extra_log2n}")
+    if xl and roof2 is not None:
+        t = f"2p{args.extra_log2n}"
+        flat.update({f"ms_per_step_{t}": xl["ms_per_step"], f"value_{t}": xl["value"], f"window_bits_{t}": xl["window_bits"],
+                     f"num_windows_{t}": xl["num_windows"], f"sort_ms_{t}": xl["phases_ms"].get("scatter_ms"),
+                     f"accumulate_ms_{t}": xl["phases_ms"].get("accumulate_ms"), f"reduce_ms_{t}": xl["phases_ms"].get("reduce_ms"),
+                     f"final_ms_{t}": xl["phases_ms"].get("final_ms"), f"mac_issue_frac_{t}": roof2["mac_issue"]["frac"],
+                     f"hbm_frac_{t}": roof2["frac"]})
+        roof.update({f"kernel_ms_{t}": roof2["kernel_ms"], f"achieved_{t}": roof2["achieved"], f"frac_{t}": roof2["frac"],
+                     f"mac_issue_frac_{t}": roof2["mac_issue"]["frac"], f"traffic_{t}": roof2["traffic"]})
+    for key, tag in (("r32_bases", "r32"), ("pipelined", "pipelined"), ("end_to_end", "end_to_end"), ("host_entry", "host_entry"),
+                     ("precomputed", "precomputed"), ("config2_bls12_377_g1_2p22", "config2_bls12_377_g1_2p22"),
+                     ("config4_shard_bw6_761_g1_2p21", "config4_bw6_761_g1_2p21"),
+                     ("config4_shard_bls12_377_g2_2p21", "config4_bls12_377_g2_2p21"),
+                     ("config4_shard_pair_together", "config4_pair_together"),
+                     ("config4_total_bw6_761_g1_2p24", "config4_bw6_761_g1_2p24"),
+                     ("config4_total_bls12_377_g2_2p24", "config4_bls12_377_g2_2p24"),
+                     ("shard_alt_bn128_g1_2p23", "shard_2p23")):
+        leg = legs.get(key)
+        if leg and leg.get("ms_per_step") is not None:
+            flat[f"ms_per_step_{tag}"] = leg["ms_per_step"]
+            flat[f"value_{tag}"] = leg["value"]
+            if "roofline" in leg:
+                flat[f"mac_issue_frac_{tag}"] = leg["roofline"]["mac_issue"]["frac"]
+                flat[f"accumulate_ms_{tag}"] = leg["roofline"]["kernel_ms"]
+    for lg in (24, 25):
+        if f"shard_alt_bn128_g1_2p{lg}" in legs:
+            flat[f"ms_per_step_shard_2p{lg}"] = legs[f"shard_alt_bn128_g1_2p{lg}"]["ms_per_step"]
+    if xl and "shard_alt_bn128_g1_2p23" in legs and (args.curve, group, args.extra_log2n) == ("alt_bn128", 1, 26):
+        # strong scaling of configs[3] as ONE GPU can predict it: whole input / (N x (shard + exchange)); the exchange
+        # (all-gather of N partial points + k_sum_points) is taken as 0.05 ms -- not a measurement of N GPUs
+        for lg, ng in ((25, 2), (24, 4), (23, 8)):
+            leg = legs.get(f"shard_alt_bn128_g1_2p{lg}")
+            if leg:
+                flat[f"predicted_efficiency_{ng}gpu"] = xl["ms_per_step"] / (ng * (leg["ms_per_step"] + 0.05))
+    if "batched" in legs:
+        flat["ms_per_msm_batched"] = legs["batched"]["ms_per_msm"]
+        flat["value_batched"] = legs["batched"]["value"]
     if roof2 is not None:
         roof[f"at_2p{args.extra_log2n}"] = {k: roof2[k] for k in ("achieved", "frac", "traffic", "traffic_source",
                                                                   "algorithmic_bytes_per_launch", "kernel_ms", "mac_issue")}
@@ -679,6 +747,7 @@ def single_gpu(args, tm, eng, dev, curve, group):
             "endomorphism_split": plan["endomorphism"],
             "parallelism": "1 GPU",
             "msms_in_flight": msm.depth,
+            **flat,
             "phases_ms": mean_phases(phases),
             "legs": legs,
         },

@@ -64,6 +64,7 @@ struct base_entry {
     void *d_aff = nullptr;
     void *d_endo = nullptr;   // phi(P) records of the whole vector (endomorphism split), built at first use
     bool automatic = false;   // created by AMDMSM_BASE_CACHE, evictable
+    bool pinned = false;      // resolved by the batch call that is running: not evictable until it returns
     uint64_t last_use = 0;
     size_t aff_bytes = 0;     // bytes of one compact affine record of this entry's group
     // HBM held by the entry: the affine copy and, once built, the phi(P) records
@@ -794,7 +795,7 @@ int msm_device_ranges(amdmsm_ctx *ctx, const group_vtable *vt, const uint32_t *d
     if (n <= maxr) return msm_device_impl(ctx, vt, d_bases, d_scalars, n, d_out, opts);
     const size_t parts = (n + maxr - 1) / maxr;
     if (parts > MAX_RANGES) return fail(ctx, AMDMSM_ERR_TOO_LARGE, "input too large for one call");
-    const size_t one = n / parts;
+    const size_t one = (n + parts - 1) / parts;   // <= maxr: no range exceeds the limit, the last one takes what is left
     const size_t xyz_bytes = (size_t)vt->el_words * 12, aff_bytes = (size_t)vt->el_words * 8, fr_bytes = (size_t)vt->fr_words * 4;
     int rc = ensure_partials(ctx);
     if (rc) return rc;
@@ -1440,9 +1441,11 @@ void *auto_cache_bases(amdmsm_ctx *ctx, const group_vtable *vt, const void *base
             const base_entry &e = ctx->bases[i];
             if (!e.automatic) continue;
             used += 2 * e.n * e.aff_bytes;
+            if (e.pinned) continue;   // a vector the running batch already resolved: its device copy must outlive the call
             if (lru == (size_t)-1 || e.last_use < ctx->bases[lru].last_use) lru = i;
         }
-        if (used + need <= cap || lru == (size_t)-1) break;
+        if (used + need <= cap) break;
+        if (lru == (size_t)-1) return nullptr;   // what is left is pinned by the running call: no room, the caller uploads
         drop_entry(ctx, lru);
     }
     if (register_bases_impl(ctx, vt, bases, stride, form, n, true, nullptr) != AMDMSM_OK) return nullptr;
@@ -1554,7 +1557,7 @@ int host_msm_ranges(amdmsm_ctx *ctx, const group_vtable *vt, const void *bases_x
     if (n <= maxr) return host_msm_enqueue(ctx, vt, bases_xyz, stride, base_form, scalars, n, opts, want_stats);
     const size_t parts = (n + maxr - 1) / maxr;
     if (parts > MAX_RANGES) return fail(ctx, AMDMSM_ERR_TOO_LARGE, "input too large for one call");
-    const size_t one = n / parts;
+    const size_t one = (n + parts - 1) / parts;   // <= maxr (see msm_device_ranges)
     const size_t xyz_bytes = (size_t)vt->el_words * 12, fr_bytes = (size_t)vt->fr_words * 4;
     int rc = ensure_partials(ctx);
     if (rc) return rc;
@@ -1663,10 +1666,21 @@ int amdmsm_multi_exp_batch(amdmsm_ctx *ctx, int curve, int group, int k, const v
     const uint32_t *d_b[MAX_BATCH], *d_s[MAX_BATCH];
     uint32_t *d_o[MAX_BATCH];
     int missing = 0;
+    // Every resident vector this batch resolves is pinned until the call returns: registering vector j under
+    // AMDMSM_BASE_CACHE_MB evicts least-recently-used automatic entries (hipFree), which must never be the copy behind
+    // d_b[j'] of an earlier j'.  A vector that does not fit beside the pinned ones is uploaded like an unregistered one.
+    struct unpin_all {
+        amdmsm_ctx *c;
+        ~unpin_all() {
+            for (auto &e : c->bases) e.pinned = false;
+        }
+    } unpin{ctx};
     for (int j = 0; j < k; ++j) {
-        d_b[j] = (const uint32_t *)find_resident_bases(ctx, vt, bases_xyz[j], stride, base_form, n);
+        base_entry *be = nullptr;
+        d_b[j] = (const uint32_t *)find_resident_bases(ctx, vt, bases_xyz[j], stride, base_form, n, &be);
         if (!d_b[j] && auto_cache_bases(ctx, vt, bases_xyz[j], stride, base_form, n))
-            d_b[j] = (const uint32_t *)find_resident_bases(ctx, vt, bases_xyz[j], stride, base_form, n);
+            d_b[j] = (const uint32_t *)find_resident_bases(ctx, vt, bases_xyz[j], stride, base_form, n, &be);
+        if (d_b[j] && be) be->pinned = true;
         if (!d_b[j]) ++missing;
     }
     if (missing) {

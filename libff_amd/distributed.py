@@ -23,8 +23,12 @@ def shard_range(total, world_size, rank):
     return lo, hi
 
 
-def all_gather_partials(partial_words, group=None):
-    """all-gather one partial point (1-D integer tensor) from every rank -> (world, words)."""
+def all_gather_partials(partial_words, group=None, out=None):
+    """all-gather one partial point (1-D integer tensor) from every rank -> (world, words).
+
+    ``out``: a preallocated contiguous (world, words) tensor on the partial's device that receives the points
+    (one ``all_gather_into_tensor``: no per-step allocation, no list of N tensors, no ``torch.stack`` -- the payload
+    is 96-288 bytes per rank, so those were most of the step's exchange time)."""
     import torch
     import torch.distributed as dist
 
@@ -33,12 +37,16 @@ def all_gather_partials(partial_words, group=None):
         # rehearsal of the multi-rank path with gloo (several ranks sharing one GPU, where RCCL
         # refuses duplicate devices): stage through the host.  .cpu() waits for the producing stream.
         host = partial_words.cpu()
-        out = [torch.empty_like(host) for _ in range(world)]
-        dist.all_gather(out, host, group=group)
-        return torch.stack(out, dim=0).to(partial_words.device, non_blocking=False)
-    out = [torch.empty_like(partial_words) for _ in range(world)]
-    dist.all_gather(out, partial_words, group=group)
-    return torch.stack(out, dim=0)
+        gathered = torch.empty((world, host.numel()), dtype=host.dtype)
+        dist.all_gather_into_tensor(gathered.view(-1), host, group=group)   # flat: gloo accepts only the 1-D form
+        if out is not None:
+            out.copy_(gathered)
+            return out
+        return gathered.to(partial_words.device, non_blocking=False)
+    if out is None:
+        out = torch.empty((world, partial_words.numel()), dtype=partial_words.dtype, device=partial_words.device)
+    dist.all_gather_into_tensor(out.view(-1), partial_words, group=group)
+    return out
 
 
 def sharded_multi_exp(local_msm, combine, group=None):
@@ -78,6 +86,9 @@ class ShardedMsm:
         words = self.sz["g_bytes"] // 8
         self.partial = [torch.zeros(words, dtype=torch.int64, device=dev) for _ in range(depth)]
         self.result = [torch.zeros(words, dtype=torch.int64, device=dev) for _ in range(depth)]
+        # receive buffers of the exchange, one per step in flight, owned here: (world, words), filled by ONE
+        # all_gather_into_tensor per step (allocated at first use, when the process group is known to be up)
+        self.gathered = [None] * depth
         # Always explicit, non-default streams: torch's default stream has handle 0, which the C ABI
         # reads as "the context's own stream" -- a non-blocking stream that does not synchronise
         # with torch's legacy null stream, so the all-gather (ordered by torch's current stream)
@@ -115,10 +126,19 @@ class ShardedMsm:
                                    partial.data_ptr(), out_form=OUT_JACOBIAN, window_bits=window_bits,
                                    stream=stream.cuda_stream)
             slot = self.engine.last_slot()
-            stacked = all_gather_partials(partial, group=self.pg).contiguous()
+            stacked = all_gather_partials(partial, group=self.pg, out=self._gather_buf(i))
             self.engine.sum_points_device(self.curve, self.group_id, stacked.data_ptr(), stacked.shape[0], out_form,
                                           result.data_ptr(), stream=stream.cuda_stream)
         return result, slot
+
+    def _gather_buf(self, i):
+        import torch.distributed as dist
+
+        if self.gathered[i] is None:
+            world = dist.get_world_size(self.pg)
+            self.gathered[i] = self.torch.zeros((world, self.partial[i].numel()), dtype=self.partial[i].dtype,
+                                                device=self.partial[i].device)
+        return self.gathered[i]
 
     def exchange_only(self, out_form):
         """The exchange step alone on slot 0's buffers (all-gather of the current partial + local sum):
@@ -126,7 +146,7 @@ class ShardedMsm:
         torch = self.torch
         stream = self.streams[0]
         with torch.cuda.stream(stream):
-            stacked = all_gather_partials(self.partial[0], group=self.pg).contiguous()
+            stacked = all_gather_partials(self.partial[0], group=self.pg, out=self._gather_buf(0))
             self.engine.sum_points_device(self.curve, self.group_id, stacked.data_ptr(), stacked.shape[0], out_form,
                                           self.result[0].data_ptr(), stream=stream.cuda_stream)
         return self.result[0]

@@ -637,3 +637,39 @@ def test_multi_exp_batch_host_entry(engine, port):
         assert (got[0] == wants[0]).all()
     finally:
         engine.unregister_bases(h)
+
+
+def test_multi_exp_batch_with_base_cache_smaller_than_the_batch():
+    """AMDMSM_BASE_CACHE_MB registers the base vectors a host call sees and evicts least-recently-used ones when the cap is
+    reached.  A batch of four vectors against a cap that holds two of them (an entry is charged twice its affine bytes):
+    registering the later vectors must not free the copies the batch already resolved for the earlier ones -- they are
+    pinned for the duration of the call and the vectors that do not fit are uploaded like unregistered ones.  Run twice
+    (the second call finds some vectors cached, in a different LRU order), each result against the oracle.  Child process:
+    the cap is read once per process."""
+    import subprocess
+
+    code = r'''
+import os, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np
+import libff_amd
+from oracle import port
+port.build()
+e = libff_amd.Engine(0)
+curve, group, n, k = 0, 1, 1 << 14, 4          # 4 x 2 x 2^14 x 64 B = 8 MiB wanted, cap 5 MiB
+bases = [port.bases_seq(curve, group, n, first=1000 * j) for j in range(k)]
+scs = [port.scalars_sha512(curve, 300 + j, n) for j in range(k)]
+wants = [port.multi_exp(curve, group, b, s, port.BDLO12_SIGNED, port.FORM_SPECIAL, chunks=8, omp=True) for b, s in zip(bases, scs)]
+for rep in range(3):
+    order = list(range(k)) if rep != 1 else [2, 0, 3, 1]
+    got = e.multi_exp_batch(curve, group, [bases[j] for j in order], [scs[j] for j in order],
+                            base_form=libff_amd.multi_exp_base_form_special)
+    for pos, j in enumerate(order):
+        assert (got[pos] == wants[j]).all(), (rep, j)
+    # single calls in between reshuffle the LRU order
+    assert (e.multi_exp(curve, group, bases[3], scs[3], base_form=libff_amd.multi_exp_base_form_special) == wants[3]).all()
+print("cache-batch-ok")
+''' % (REPO, os.path.join(REPO, "tests"))
+    env = dict(os.environ, AMDMSM_BASE_CACHE_MB="5")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and "cache-batch-ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])

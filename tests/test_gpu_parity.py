@@ -241,6 +241,52 @@ def test_full_size_closed_form_and_sharding(engine, port, name, curve, group, lo
     assert (got == want).all()
 
 
+def _r32_closed_form(port, curve, group, scalars_mont, p32):
+    """sum_i s_i P_(i mod 32) = sum_j (sum_(i = j mod 32) s_i) P_j: 32 oracle scalar multiplications and 31 additions, affine."""
+    plain = port.fr_as_bigint(curve, scalars_mont)
+    n, fl = plain.shape
+    assert n % 32 == 0 and n // 32 <= (1 << 31)
+    r = to_int(golden()[f"{libff_amd.engine.CURVE_NAMES[curve]}_g1/fr_modulus"])
+    lo = (plain & np.uint64(0xFFFFFFFF)).reshape(n // 32, 32, fl).sum(axis=0, dtype=np.uint64)
+    hi = (plain >> np.uint64(32)).reshape(n // 32, 32, fl).sum(axis=0, dtype=np.uint64)
+    acc = None
+    for j in range(32):
+        k = sum((int(lo[j, t]) << (64 * t)) + (int(hi[j, t]) << (64 * t + 32)) for t in range(fl)) % r
+        k_plain = np.array([[(k >> (64 * t)) & 0xFFFFFFFFFFFFFFFF for t in range(fl)]], dtype=np.uint64)
+        term = port.scalar_mul(curve, group, p32[j], port.fr_from_bigint(curve, k_plain)[0])
+        acc = term if acc is None else port.group_op(curve, group, 0, acc, term)
+    return port.group_op(curve, group, 4, acc)
+
+
+@pytest.mark.parametrize("name,curve,group,log2n", [("alt_bn128_g1", 0, 1, 20), ("alt_bn128_g1", 0, 1, 22),
+                                                     ("bls12_377_g1", 1, 1, 20), ("bls12_377_g2", 1, 2, 18)])
+def test_profiler_shaped_bases_r32_closed_form(engine, port, name, curve, group, log2n):
+    """The reference profiler's own input shape at scale (profile_multiexp.cpp:14-15, 24-50: 32 distinct points repeated,
+    SHA512_rng scalars): every bucket receives the same few points over and over, so the equal-point (doubling) and
+    opposite-point (infinity) branches of the bucket addition (rr.cuh xyzz_rr_same_x; alt_bn128_g1.cpp:208-283) run at the
+    collision rate the profiler produces.  Expected value from 32 oracle scalar multiplications; with the endomorphism
+    split permitted and with it forbidden, and at a second window size."""
+    n = 1 << log2n
+    sc = port.scalars_sha512(curve, 0, n)
+    p32 = port.bases_r32(curve, group, 32)
+    bases = np.ascontiguousarray(np.tile(p32, (n // 32, 1)))
+    assert (bases[:96] == port.bases_r32(curve, group, 96)).all()
+    want = _r32_closed_form(port, curve, group, sc, p32)
+    saved = engine.endomorphism
+    try:
+        for endo in (1, -1):   # libff's own points lie in the order-r subgroup: the split is permitted; -1: never
+            engine.endomorphism = endo
+            got = engine.multi_exp(curve, group, bases, sc, base_form=multi_exp_base_form_special, out_form=libff_amd.OUT_AFFINE)
+            assert (got == want).all(), f"endomorphism={endo}"
+        engine.endomorphism = 0
+        auto_c = libff_amd.plan(curve, group, n)["c"]
+        got = engine.multi_exp(curve, group, bases, sc, base_form=multi_exp_base_form_special, window_bits=auto_c - 2,
+                               out_form=libff_amd.OUT_AFFINE)
+        assert (got == want).all()
+    finally:
+        engine.endomorphism = saved
+
+
 @pytest.mark.parametrize("name,curve,group", [GROUPS[0], GROUPS[2], GROUPS[3]])
 def test_skewed_scalars(engine, port, name, curve, group):
     """Witness-like scalar vectors (multiexp.tcc:690-757 exists because of them): mostly 0 / 1 /
@@ -724,5 +770,44 @@ def test_points_of_order_two_in_one_bucket(engine, port, name, curve, group, x_p
     sc = port.scalars_sha512(curve, 78, n)
     bases[::7] = t
     sc[::7] = sc[0]
+    want = port.multi_exp(curve, group, bases, sc, port.BDLO12_SIGNED, 1)
+    assert (engine.multi_exp(curve, group, bases, sc, base_form=multi_exp_base_form_special) == want).all()
+
+
+@pytest.mark.parametrize("name,curve,group", [GROUPS[1], GROUPS[3], GROUPS[7]])
+def test_equal_and_opposite_points_in_one_bucket_fq2(engine, port, name, curve, group):
+    """The Fq2 lane-pair path of the reduced-radix loop (rr.cuh Rr2H: predicates made pair-uniform over DPP, a record's two
+    components exported by neighbouring lanes) through k_accumulate against the oracle: copies of one point with one scalar
+    (first addition doubles: mixed_add -> dbl, alt_bn128_g2.cpp:208-283), a point and its negative with one scalar (the bucket
+    returns to infinity and is then refilled), and a bucket whose points cancel altogether (an all-zero record)."""
+    n = 64
+    bases = port.bases_seq(curve, group, n, first=5)
+    sc = port.scalars_sha512(curve, 91, n)
+    neg = port.group_op(curve, group, 3, bases[7])
+    for i in (7, 12, 20):          # three copies of one point, one scalar: doubling, then a general addition
+        bases[i] = bases[7]
+        sc[i] = sc[7]
+    bases[30] = neg                # ... and its negative with the same scalar
+    sc[30] = sc[7]
+    bases[41] = port.group_op(curve, group, 3, bases[40])   # P, -P alone in their buckets: every window's sum cancels
+    sc[41] = sc[40]
+    want = port.multi_exp(curve, group, bases, sc, port.BDLO12_SIGNED, 1)
+    saved = engine.endomorphism
+    try:
+        for endo in (-1, 1):
+            engine.endomorphism = endo
+            for c in (0, 3, 9):
+                got = engine.multi_exp(curve, group, bases, sc, base_form=multi_exp_base_form_special, window_bits=c)
+                assert (got == want).all(), (endo, c)
+    finally:
+        engine.endomorphism = saved
+    # spread through a larger input: every seventh base the same point with the same scalar
+    n = 2000
+    bases = port.bases_seq(curve, group, n, first=1)
+    sc = port.scalars_sha512(curve, 92, n)
+    bases[::7] = bases[0]
+    sc[::7] = sc[0]
+    bases[3::14] = port.group_op(curve, group, 3, bases[0])
+    sc[3::14] = sc[0]
     want = port.multi_exp(curve, group, bases, sc, port.BDLO12_SIGNED, 1)
     assert (engine.multi_exp(curve, group, bases, sc, base_form=multi_exp_base_form_special) == want).all()
