@@ -28,8 +28,17 @@
 //
 // Data crosses the boundary without conversion: &*vec_start is handed to the C ABI as the
 // libff in-memory records (Montgomery limbs, (X, Y, Z)), sizeof(T) is the stride.
+// Small inputs: a device MSM has a floor of about 0.7 ms (launch chain, bucket reduction, final
+// Horner) whatever its size, while the reference runs a handful of points straight through its
+// inner loop in microseconds (multiexp.tcc:655-661).  Calls with fewer than
+// libff_amd::small_input_threshold() points (default 32; AMDMSM_CPU_BELOW in the environment; 0
+// sends every size to the device) therefore run the CALLER'S OWN libff body -- the reference's
+// generic multi_exp / multi_exp_filter_one_zero, instantiated in the caller's translation unit
+// through a field tag type the specialisations below do not capture.  Nothing of that is compiled
+// into libamdmsm.so.
 // Errors: the reference has none on this path (asserts only); an engine failure (no GPU,
-// HIP error) throws std::runtime_error -- there is no silent CPU fallback.
+// HIP error) throws std::runtime_error -- there is no silent CPU fallback for inputs at or above
+// the threshold.
 #ifndef LIBFF_AMD_MULTIEXP_HPP_
 #define LIBFF_AMD_MULTIEXP_HPP_
 
@@ -145,6 +154,51 @@ inline int &endomorphism_mode()
 {
     static int m = 0;
     return m;
+}
+
+/// Inputs with fewer points than this run the caller's own libff CPU body (see the header comment).
+/// Measured crossover (profiles/r04_profile_sweep.csv): the device's host entry costs 0.7-1.6 ms for
+/// any small n, the reference ~50 us (alt_bn128 G1) to ~200 us (bw6_761) per point on one core.
+inline size_t &small_input_threshold()
+{
+    static size_t n = [] {
+        const char *env = std::getenv("AMDMSM_CPU_BELOW");
+        return env && *env ? (size_t)std::atol(env) : (size_t)32;
+    }();
+    return n;
+}
+
+/// FieldT under another name: multi_exp_implementation<GroupT, reference_path_field<FieldT>, ...> is not
+/// one of the routed (GroupT, FieldT) pairs, so it selects the reference's generic bodies
+/// (multiexp.tcc:276-381, 507-633) for the very same group and field arithmetic.
+template<typename FieldT> struct reference_path_field : public FieldT {
+    reference_path_field() = default;
+    reference_path_field(const FieldT &f) : FieldT(f) {}
+};
+
+/// libff::multi_exp / multi_exp_filter_one_zero of the reference itself (its chunk split and OpenMP
+/// loop included, multiexp.tcc:643-688, 690-757) on a copy of the scalars under the tag type.
+template<
+    typename GroupT,
+    typename FieldT,
+    libff::multi_exp_method Method,
+    libff::multi_exp_base_form BaseForm>
+GroupT reference_multi_exp(
+    typename std::vector<GroupT>::const_iterator vec_start,
+    typename std::vector<GroupT>::const_iterator vec_end,
+    typename std::vector<FieldT>::const_iterator scalar_start,
+    typename std::vector<FieldT>::const_iterator scalar_end,
+    const size_t chunks,
+    bool filter_one_zero)
+{
+    typedef reference_path_field<FieldT> TagT;
+    const std::vector<TagT> tmp(scalar_start, scalar_end);
+    if (filter_one_zero) {
+        return libff::multi_exp_filter_one_zero<GroupT, TagT, Method, BaseForm>(
+            vec_start, vec_end, tmp.cbegin(), tmp.cend(), chunks);
+    }
+    return libff::multi_exp<GroupT, TagT, Method, BaseForm>(
+        vec_start, vec_end, tmp.cbegin(), tmp.cend(), chunks);
 }
 
 /// (curve, group) ids of the C ABI for a libff group type; specialised below
@@ -405,6 +459,10 @@ std::vector<GroupT> gpu_batch_exp(
         std::vector<FIELD_T>::const_iterator scalar_end,                       \
         const size_t chunks)                                                   \
     {                                                                          \
+        if ((size_t)(vec_end - vec_start) < libff_amd::small_input_threshold()) { \
+            return libff_amd::reference_multi_exp<GROUP_T, FIELD_T, METHOD, FORM>( \
+                vec_start, vec_end, scalar_start, scalar_end, chunks, false);  \
+        }                                                                      \
         return libff_amd::gpu_multi_exp<GROUP_T, FIELD_T, FORM>(               \
             vec_start, vec_end, scalar_start, scalar_end, chunks);             \
     }                                                                          \
@@ -416,6 +474,10 @@ std::vector<GroupT> gpu_batch_exp(
         std::vector<FIELD_T>::const_iterator scalar_end,                       \
         const size_t chunks)                                                   \
     {                                                                          \
+        if ((size_t)(vec_end - vec_start) < libff_amd::small_input_threshold()) { \
+            return libff_amd::reference_multi_exp<GROUP_T, FIELD_T, METHOD, FORM>( \
+                vec_start, vec_end, scalar_start, scalar_end, chunks, true);   \
+        }                                                                      \
         return libff_amd::gpu_multi_exp_filter_one_zero<GROUP_T, FIELD_T, FORM>( \
             vec_start, vec_end, scalar_start, scalar_end, chunks);             \
     }
@@ -447,6 +509,10 @@ std::vector<GroupT> gpu_batch_exp(
             typename std::vector<FIELD_T>::const_iterator exponents,           \
             typename std::vector<FIELD_T>::const_iterator exponents_end)       \
         {                                                                      \
+            if ((size_t)(bases_end - bases) < libff_amd::small_input_threshold()) { \
+                return libff_amd::reference_multi_exp<GROUP_T, FIELD_T, multi_exp_method_BDLO12_signed, BaseForm>( \
+                    bases, bases_end, exponents, exponents_end, 1, false);     \
+            }                                                                  \
             return libff_amd::gpu_multi_exp_inner<GROUP_T, FIELD_T, BaseForm>( \
                 bases, bases_end, exponents, exponents_end);                   \
         }                                                                      \
@@ -465,6 +531,10 @@ std::vector<GroupT> gpu_batch_exp(
             typename std::vector<FIELD_T>::const_iterator exponents,           \
             typename std::vector<FIELD_T>::const_iterator exponents_end)       \
         {                                                                      \
+            if ((size_t)(bases_end - bases) < libff_amd::small_input_threshold()) { \
+                return libff_amd::reference_multi_exp<GROUP_T, FIELD_T, multi_exp_method_BDLO12, BaseForm>( \
+                    bases, bases_end, exponents, exponents_end, 1, false);     \
+            }                                                                  \
             return libff_amd::gpu_multi_exp_inner<GROUP_T, FIELD_T, BaseForm>( \
                 bases, bases_end, exponents, exponents_end);                   \
         }                                                                      \

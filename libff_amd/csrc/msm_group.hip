@@ -1023,6 +1023,62 @@ AMDMSM_DEV void acc_add(acc_state& s, const uint32_t* rec, bool neg) {
 
 constexpr uint32_t NO_BUCKET = 0xffffffffu;
 
+// A record of the bucket / partial arrays (ZZS words) comes in two forms:
+//   * as k_accumulate wrote it (AMDMSM_ACC_RR): 4 L reduced-radix limbs per component, all zero = infinity;
+//   * canonical (X, Y, ZZ, ZZZ) words at the start of the record, as the fix-up kernels write their sums, with a mark
+//     in the record's last word -- a word the canonical layout leaves free (ZZS > ZZW) and that in the limb form is the
+//     top limb of ZZZ: a product's output or the constant one, far below 2^30 in magnitude, so that its bits 30 and 31
+//     are equal there.
+// Every reader takes either (load_xyzz_rec): the limb form is turned into canonical words in registers -- one product by a
+// power of two and one exact normalisation per coordinate (rr_export_component) -- which used to be a pass of its own over
+// all records, read or not (k_rr_export: a memory round trip of 272 B per record, 3 % of a 2^20-point MSM).
+#if AMDMSM_ACC_RR
+static_assert(ZZS > ZZW, "a canonical record leaves the last word of the limb record free");
+constexpr uint32_t REC_CANON_MARK = 0x40000000u;
+template <class P, bool I> AMDMSM_DEV uint32_t (&lane_words(Fp<P, I>& a))[P::N] { return a.v; }
+template <class P, int NR> AMDMSM_DEV uint32_t (&lane_words(Fp2H<P, NR>& a))[P::N] { return a.h.v; }
+template <class T>
+AMDMSM_DEV void load_xyzz_rec(Xyzz<T>& p, const uint32_t* q) {
+    const uint32_t mk = q[ZZS - 1];
+    if (((mk ^ (mk << 1)) >> 31) != 0) {   // canonical words
+        load_xyzz(p, q);
+        return;
+    }
+    // this lane's component: 4 L limbs (an Fq2 record: the even lane of the pair takes component 0, the odd lane 1)
+    const uint4* q4 = reinterpret_cast<const uint4*>(q + (GP::DEG == 2 && (threadIdx.x & 1u) ? 4 * RRL : 0));
+    uint32_t w[4 * RRL];
+#pragma unroll
+    for (int k = 0; k < RRL; ++k) {
+        const uint4 v = q4[k];
+        w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
+    }
+    constexpr int D = rr_shape<FQ>::D;
+    Rr<FQ> a;
+    // (zero limbs give zero words: an all-zero record reads as ZZ == 0, infinity; a zero component of a finite Fq2
+    // point stays zero)
+#pragma unroll
+    for (int k = 0; k < RRL; ++k) a.v[k] = (int32_t)w[k];
+    rr_export_component<FQ, 0>(lane_words(p.x), a);
+#pragma unroll
+    for (int k = 0; k < RRL; ++k) a.v[k] = (int32_t)w[RRL + k];
+    rr_export_component<FQ, 0>(lane_words(p.y), a);
+#pragma unroll
+    for (int k = 0; k < RRL; ++k) a.v[k] = (int32_t)w[2 * RRL + k];
+    rr_export_component<FQ, D>(lane_words(p.zz), a);
+#pragma unroll
+    for (int k = 0; k < RRL; ++k) a.v[k] = (int32_t)w[3 * RRL + k];
+    rr_export_component<FQ, D>(lane_words(p.zzz), a);
+}
+template <class T>
+AMDMSM_DEV void store_xyzz_rec(uint32_t* q, const Xyzz<T>& p) {
+    store_xyzz(q, p);
+    q[ZZS - 1] = REC_CANON_MARK;   // (both lanes of an Fq2 pair write the same word)
+}
+#else
+template <class T> AMDMSM_DEV void load_xyzz_rec(Xyzz<T>& p, const uint32_t* q) { load_xyzz(p, q); }
+template <class T> AMDMSM_DEV void store_xyzz_rec(uint32_t* q, const Xyzz<T>& p) { store_xyzz(q, p); }
+#endif
+
 // smallest b with e[b] > k   (e non-decreasing, e[B-1] > k)
 AMDMSM_DEV uint32_t bucket_of_entry(const uint32_t* __restrict__ e, uint32_t B, uint32_t k) {
     uint32_t l = 0, r = B - 1;
@@ -1225,51 +1281,6 @@ __global__ void __launch_bounds__(TPB, AMDMSM_ACC_WAVES) k_accumulate(const uint
     }
 }
 
-#if AMDMSM_ACC_RR
-// Every record k_accumulate wrote (buckets, part_first, part_last: 4 L reduced-radix limbs per component, ZZS words
-// apart) becomes canonical (X, Y, ZZ, ZZZ) words at the start of the same record.  One thread per (record, component);
-// the two threads of an Fq2 record are neighbours in a wave: both have read their limbs before either writes.
-// Records nobody wrote hold zeros (buckets: infinity) or leftovers (partials the fix-up does not look at): both pass
-// through harmlessly.
-__global__ void __launch_bounds__(TPB) k_rr_export(uint32_t* __restrict__ buckets, size_t n_buckets, uint32_t* __restrict__ part_first,
-                                                   uint32_t* __restrict__ part_last, size_t n_lanes) {
-    const size_t t = gtid();
-    const size_t i = t / GP::DEG;
-    const uint32_t comp = (uint32_t)(t % GP::DEG);
-    const bool live = i < n_buckets + 2 * n_lanes;
-    uint32_t* q = !live ? buckets
-                        : (i < n_buckets ? buckets + i * ZZS
-                                         : (i < n_buckets + n_lanes ? part_first + (i - n_buckets) * ZZS : part_last + (i - n_buckets - n_lanes) * ZZS));
-    uint32_t w[4 * RRL];
-    const uint4* q4 = reinterpret_cast<const uint4*>(q + comp * 4 * RRL);
-    uint32_t any = 0;
-#pragma unroll
-    for (int k = 0; k < RRL; ++k) {
-        const uint4 v = live ? q4[k] : make_uint4(0, 0, 0, 0);
-        w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
-        any |= v.x | v.y | v.z | v.w;
-    }
-    // an Fq2 record is infinity when BOTH components are all zero; a zero component of a finite point must still be
-    // written (its words move)
-    bool rec_zero = any == 0;
-    if (GP::DEG == 2) rec_zero = rec_zero && (rr_pair_swap(any == 0 ? 1 : 0) != 0);
-    if (!live || rec_zero) return;
-    constexpr int D = rr_shape<FQ>::D;
-    Rr<FQ> a;
-    uint32_t out[FQ::N];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-#pragma unroll
-        for (int k = 0; k < RRL; ++k) a.v[k] = (int32_t)w[j * RRL + k];
-        if (j < 2) rr_export_component<FQ, 0>(out, a);
-        else rr_export_component<FQ, D>(out, a);
-        uint4* o4 = reinterpret_cast<uint4*>(q + (j * GP::DEG + comp) * FQ::N);
-#pragma unroll
-        for (int k = 0; k < FQ::N / 4; ++k) o4[k] = make_uint4(out[4 * k], out[4 * k + 1], out[4 * k + 2], out[4 * k + 3]);
-    }
-}
-#endif
-
 AMDMSM_DEV void wave_group_sum(Jac<E>& p, uint32_t G);
 AMDMSM_DEV void wave_group_sum_r(Jac<ER>& p, uint32_t G);
 
@@ -1298,12 +1309,22 @@ AMDMSM_DEV uint32_t* fixup_queue_base(uint32_t* q, size_t lanes, int mid) {
 // (The fix-up kernels hold their elements as the bucket reduction does -- ER: an Fq2 element over a pair of lanes for the
 // groups built with AMDMSM_ACC_SPLIT, RED_LANES physical lanes per logical lane -- so that they are not the one-wave-per-SIMD
 // kernels with spill space the packed form made them: bls12_377 G2 2^21 fix-up 1.16 -> see profiles/r03_experiments.txt.)
+AMDMSM_DEV void fixup_compact_block(uint32_t blk, const uint32_t* __restrict__ ends, uint32_t* __restrict__ part_first, int W,
+                                    uint32_t B, uint32_t S, uint32_t T);
+
+// blocks [0, fix_blocks): the spans; blocks from fix_blocks on: the folding of aligned blocks inside very long spans
+// (fixup_compact_block below) -- independent work in one launch: an inline span never reaches a folded block's first
+// slot, which only the queue pass that follows reads
 __global__ void __launch_bounds__(64) k_accumulate_fixup(const uint32_t* __restrict__ ends,
-                                                         const uint32_t* __restrict__ part_first,
+                                                         uint32_t* __restrict__ part_first,
                                                          const uint32_t* __restrict__ part_last,
                                                          const uint32_t* __restrict__ cont_bucket,
                                                          uint32_t* __restrict__ buckets, uint32_t* __restrict__ queue,
-                                                         int W, uint32_t B, uint32_t S, uint32_t T) {
+                                                         int W, uint32_t B, uint32_t S, uint32_t T, uint32_t fix_blocks) {
+    if (blockIdx.x >= fix_blocks) {
+        fixup_compact_block(blockIdx.x - fix_blocks, ends, part_first, W, B, S, T);
+        return;
+    }
     const size_t g = gtid() / RED_LANES;
     const bool first_of_pair = (threadIdx.x % RED_LANES) == 0;
     const size_t w = g / T;
@@ -1334,14 +1355,14 @@ __global__ void __launch_bounds__(64) k_accumulate_fixup(const uint32_t* __restr
     }
     if (span == 0 || span > INLINE_SPAN) return;
     Xyzz<ER> acc, x;
-    load_xyzz(acc, part_last + g * ZZS);
+    load_xyzz_rec(acc, part_last + g * ZZS);
 #ifndef AMDMSM_FIX_PRIO
 #define AMDMSM_FIX_PRIO 1
 #endif
     // priority falling with progress, as in k_accumulate: the waves of a SIMD end together
     if (AMDMSM_FIX_PRIO) __builtin_amdgcn_s_setprio(3);
     for (uint32_t u = t + 1; u <= t_last; ++u) {
-        load_xyzz(x, part_first + (w * T + u) * ZZS);
+        load_xyzz_rec(x, part_first + (w * T + u) * ZZS);
         xyzz_add(acc, acc, x);
         if (AMDMSM_FIX_PRIO) {
             const uint32_t done = (uint32_t)__builtin_amdgcn_readfirstlane((int)(u - t));
@@ -1350,7 +1371,7 @@ __global__ void __launch_bounds__(64) k_accumulate_fixup(const uint32_t* __restr
             if (done >= 3) __builtin_amdgcn_s_setprio(0);
         }
     }
-    store_xyzz(buckets + (w * B + b) * ZZS, acc);
+    store_xyzz_rec(buckets + (w * B + b) * ZZS, acc);
 }
 
 // A bucket that spans thousands of lanes (one scalar value repeated across much of the input)
@@ -1359,13 +1380,12 @@ __global__ void __launch_bounds__(64) k_accumulate_fixup(const uint32_t* __restr
 // the block's first part_first slot; the closing wave then reads one partial per block.
 constexpr uint32_t FIX_BLOCK = 256;
 
-__global__ void __launch_bounds__(64) k_accumulate_compact(const uint32_t* __restrict__ ends,
-                                                           uint32_t* __restrict__ part_first, int W, uint32_t B,
-                                                           uint32_t S, uint32_t T) {
+AMDMSM_DEV void fixup_compact_block(uint32_t blk, const uint32_t* __restrict__ ends, uint32_t* __restrict__ part_first, int W,
+                                    uint32_t B, uint32_t S, uint32_t T) {
     const uint32_t nblk = T / FIX_BLOCK;
     if (nblk < 2) return;
-    const size_t w = blockIdx.x / (nblk - 1);
-    const uint32_t k = blockIdx.x % (nblk - 1) + 1;   // block 0 has no lane before it
+    const size_t w = blk / (nblk - 1);
+    const uint32_t k = blk % (nblk - 1) + 1;   // block 0 has no lane before it
     if (w >= (size_t)W) return;
     const uint32_t* e = ends + w * B;
     const uint32_t total = e[B - 1];
@@ -1378,14 +1398,14 @@ __global__ void __launch_bounds__(64) k_accumulate_compact(const uint32_t* __res
     Xyzz<ER> acc, x;
     xyzz_set_inf(acc);
     for (uint32_t u = first + lane; u <= last; u += RED_FOLD) {
-        load_xyzz(x, part_first + (w * T + u) * ZZS);
+        load_xyzz_rec(x, part_first + (w * T + u) * ZZS);
         xyzz_add(acc, acc, x);
     }
     Jac<ER> j;
     xyzz_to_jac(j, acc);
     wave_group_sum_r(j, RED_FOLD);
     jac_to_xyzz(acc, j);
-    if (lane == 0) store_xyzz(part_first + (w * T + first) * ZZS, acc);
+    if (lane == 0) store_xyzz_rec(part_first + (w * T + first) * ZZS, acc);
 }
 
 // G lanes per queued bucket (G = 64 for the long queue, MID_G for the mid queue): the lanes
@@ -1396,9 +1416,13 @@ __global__ void __launch_bounds__(64, AMDMSM_TAIL_WAVES) k_accumulate_fixup_queu
                                                                const uint32_t* __restrict__ part_last,
                                                                const uint32_t* __restrict__ cont_bucket,
                                                                uint32_t* __restrict__ buckets,
-                                                               const uint32_t* __restrict__ queue, int mid, uint32_t G,
+                                                               const uint32_t* __restrict__ queue, uint32_t mid_blocks,
                                                                size_t lanes, uint32_t B, uint32_t S, uint32_t T) {
+    // blocks [0, mid_blocks): the mid queue (MID_G lanes per bucket); the others: the long queue (a wave per bucket)
     __builtin_amdgcn_s_setprio(3);
+    const int mid = blockIdx.x < mid_blocks ? 1 : 0;
+    uint32_t G = mid ? MID_G : 64u;
+    const uint32_t bid = mid ? blockIdx.x : blockIdx.x - mid_blocks, nblk = mid ? mid_blocks : gridDim.x - mid_blocks;
     const uint32_t count = queue[mid];
     const uint32_t* qb = queue + 2 + (mid ? 2 * fixup_queue_cap_long(lanes) : 0);
     if (G > RED_FOLD) G = RED_FOLD;   // a wave holds RED_FOLD reduction lanes
@@ -1410,7 +1434,7 @@ __global__ void __launch_bounds__(64, AMDMSM_TAIL_WAVES) k_accumulate_fixup_queu
     const uint32_t per_wave = RED_FOLD / G;
     const uint32_t rl = (threadIdx.x & 63u) / RED_LANES;   // reduction lane inside the wave
     const uint32_t sub = rl / G, lane = rl % G;
-    for (uint32_t q0 = blockIdx.x * per_wave; q0 < count; q0 += gridDim.x * per_wave) {
+    for (uint32_t q0 = bid * per_wave; q0 < count; q0 += nblk * per_wave) {
         const uint32_t q = q0 + sub;
         const bool live = q < count;
         Xyzz<ER> acc, x;
@@ -1423,7 +1447,7 @@ __global__ void __launch_bounds__(64, AMDMSM_TAIL_WAVES) k_accumulate_fixup_queu
             const uint32_t t = (uint32_t)(g % T);
             b = cont_bucket[g];
             const uint32_t t_last = (ends[w * B + b] - 1) / S;
-            if (lane == 0) load_xyzz(acc, part_last + g * ZZS);
+            if (lane == 0) load_xyzz_rec(acc, part_last + g * ZZS);
             // lanes t+1 .. t_last = head [t+1, h), nb folded blocks from h, tail [tail0, t_last]
             uint32_t h = (t + 1 + FIX_BLOCK - 1) / FIX_BLOCK * FIX_BLOCK;
             uint32_t nb = 0;
@@ -1432,7 +1456,7 @@ __global__ void __launch_bounds__(64, AMDMSM_TAIL_WAVES) k_accumulate_fixup_queu
             const uint32_t items = nh + nb + (t_last + 1 - tail0);
             for (uint32_t i = lane; i < items; i += G) {
                 const uint32_t u = i < nh ? t + 1 + i : (i < nh + nb ? h + (i - nh) * FIX_BLOCK : tail0 + (i - nh - nb));
-                load_xyzz(x, part_first + (w * T + u) * ZZS);
+                load_xyzz_rec(x, part_first + (w * T + u) * ZZS);
                 xyzz_add(acc, acc, x);
             }
         }
@@ -1440,7 +1464,7 @@ __global__ void __launch_bounds__(64, AMDMSM_TAIL_WAVES) k_accumulate_fixup_queu
         xyzz_to_jac(j, acc);
         wave_group_sum_r(j, G);
         jac_to_xyzz(acc, j);
-        if (live && lane == 0) store_xyzz(buckets + (w * B + b) * ZZS, acc);
+        if (live && lane == 0) store_xyzz_rec(buckets + (w * B + b) * ZZS, acc);
     }
 }
 
@@ -1487,7 +1511,7 @@ __global__ void __launch_bounds__(64) k_reduce_segments(const uint32_t* __restri
         xyzz_set_inf(xa);
         xyzz_set_inf(xs);
         for (uint32_t j = L; j-- > 0;) {
-            load_xyzz(xb, seg + (size_t)j * ZZS);
+            load_xyzz_rec(xb, seg + (size_t)j * ZZS);
             xyzz_add(xa, xa, xb);    // xa = sum_{k >= j} B_k
             xyzz_add(xs, xs, xa);    // xs = sum_k (k - j + 1) B_k
         }
@@ -1635,7 +1659,7 @@ __global__ void __launch_bounds__(64, AMDMSM_TAIL_WAVES) k_bucket_sums(const uin
             const uint32_t idx = j * q + i;
             const uint64_t b1 = col ? (uint64_t)idx * C + o : (uint64_t)o * C + idx;   // weight b + 1
             if (b1 >= 1 && b1 <= B) {
-                load_xyzz(xb, bk + (size_t)(b1 - 1) * ZZS);
+                load_xyzz_rec(xb, bk + (size_t)(b1 - 1) * ZZS);
                 xyzz_add(xa, xa, xb);
             }
         }
@@ -2519,7 +2543,10 @@ AMDMSM_DEV bool in_safe_subgroup(const Aff<E>& a) {
 }
 
 // status bits: 1 = coordinate out of range, 2 = not on the curve, 4 = not in the safe subgroup
-__global__ void __launch_bounds__(TPB, (AMDMSM_ACC_RR && GP::DEG == 1 && FQ::N <= 12) ? 2 : 1) k_ffi_decode_points(const uint32_t* __restrict__ src, size_t n,
+#ifndef AMDMSM_FFI_WAVES
+#define AMDMSM_FFI_WAVES ((AMDMSM_ACC_RR && GP::DEG == 1 && FQ::N <= 12) ? 2 : 1)
+#endif
+__global__ void __launch_bounds__(TPB, AMDMSM_FFI_WAVES) k_ffi_decode_points(const uint32_t* __restrict__ src, size_t n,
                                                            uint32_t* __restrict__ dst, uint32_t* __restrict__ status) {
     const size_t i = gtid();
     if (i >= n) return;
@@ -2796,10 +2823,10 @@ void l_sort(hipStream_t st, const uint32_t* scalars, size_t n, int mont, int c, 
     else
         hipLaunchKernelGGL(k_sort_fine<SORT_TPB>, dim3(nbin, We), dim3(SORT_TPB), fine_lds, st, tmp_payload, tmp_key16, coarse,
                            stride, c, hb, sg.chunk_cap, sg.big_thresh, sg.big_cap, perchunk_words, big, ends, lists);
-    hipLaunchKernelGGL(k_sort_big_hist, dim3(2048), dim3(SORT_TPB), 0, st, tmp_key16, coarse, stride, c, hb, big, ends);
+    hipLaunchKernelGGL(k_sort_big_hist, dim3(512), dim3(SORT_TPB), 0, st, tmp_key16, coarse, stride, c, hb, big, ends);
     hipLaunchKernelGGL(k_sort_big_scan, dim3(256), dim3(SORT_TPB), 0, st, coarse, c, hb, sg.big_cap, big, ends);
     const size_t big_lds = ((size_t)4 << sg.fb) * 4 + (size_t)SORT_TILE * 6;
-    hipLaunchKernelGGL(k_sort_big_scatter, dim3(2048), dim3(SORT_TPB), big_lds, st, tmp_payload, tmp_key16, coarse, stride, c,
+    hipLaunchKernelGGL(k_sort_big_scatter, dim3(512), dim3(SORT_TPB), big_lds, st, tmp_payload, tmp_key16, coarse, stride, c,
                        hb, sg.big_cap, big, lists);
 }
 size_t l_accumulate_resident_lanes(int overlap);
@@ -2842,10 +2869,7 @@ void l_accumulate(hipStream_t st, const uint32_t* ends, const uint32_t* lists, s
                        list_stride, bases, buckets, part_first, part_last, cont_bucket, W, B, S, T, endo_pts,
                        endo_pts ? (uint32_t)n_real : 0x80000000u, sync_waves);
 #endif
-#if AMDMSM_ACC_RR
-    hipLaunchKernelGGL(k_rr_export, dim3(blocks_for(((size_t)W * B + 2 * (size_t)W * T) * GP::DEG)), dim3(TPB), 0, st, buckets,
-                       (size_t)W * B, part_first, part_last, (size_t)W * T);
-#endif
+    // (no export pass: the readers of the records convert the limb form in registers, load_xyzz_rec)
 }
 void l_endo_points(hipStream_t st, const uint32_t* bases, size_t n, uint32_t* out) {
     if (!n) return;
@@ -2869,17 +2893,17 @@ size_t l_accumulate_resident_lanes(int overlap) {
 void l_accumulate_fixup(hipStream_t st, const uint32_t* ends, uint32_t* buckets, uint32_t* part_first,
                         const uint32_t* part_last, const uint32_t* cont_bucket, uint32_t* queue, int W, uint32_t B,
                         uint32_t S, uint32_t T) {
-    if (T / FIX_BLOCK >= 2)
-        hipLaunchKernelGGL(k_accumulate_compact, dim3((unsigned)(W * (T / FIX_BLOCK - 1))), dim3(64), 0, st, ends,
-                           part_first, W, B, S, T);
-    hipLaunchKernelGGL(k_accumulate_fixup, dim3(blocks_for((size_t)W * T * RED_LANES, 64)), dim3(64), 0, st, ends, part_first,
-                       part_last, cont_bucket, buckets, queue, W, B, S, T);
+    // two launches: the spans (and, in the same grid, the folding of aligned blocks inside very long spans), then both
+    // queues side by side
+    const unsigned fix_blocks = blocks_for((size_t)W * T * RED_LANES, 64);
+    const unsigned compact_blocks = T / FIX_BLOCK >= 2 ? (unsigned)(W * (T / FIX_BLOCK - 1)) : 0u;
+    hipLaunchKernelGGL(k_accumulate_fixup, dim3(fix_blocks + compact_blocks), dim3(64), 0, st, ends, part_first,
+                       part_last, cont_bucket, buckets, queue, W, B, S, T, fix_blocks);
     const size_t lanes = (size_t)W * T;
     const size_t cap_mid = fixup_queue_cap_mid(lanes) / (RED_FOLD / MID_G) + 1, cap_long = fixup_queue_cap_long(lanes);
-    hipLaunchKernelGGL(k_accumulate_fixup_queue, dim3((unsigned)(cap_mid < 8192 ? cap_mid : 8192)), dim3(64), 0, st, ends,
-                       part_first, part_last, cont_bucket, buckets, queue, 1, MID_G, lanes, B, S, T);
-    hipLaunchKernelGGL(k_accumulate_fixup_queue, dim3((unsigned)(cap_long < 2048 ? cap_long : 2048)), dim3(64), 0, st, ends,
-                       part_first, part_last, cont_bucket, buckets, queue, 0, 64u, lanes, B, S, T);
+    const unsigned mid_blocks = (unsigned)(cap_mid < 8192 ? cap_mid : 8192), long_blocks = (unsigned)(cap_long < 2048 ? cap_long : 2048);
+    hipLaunchKernelGGL(k_accumulate_fixup_queue, dim3(mid_blocks + long_blocks), dim3(64), 0, st, ends,
+                       part_first, part_last, cont_bucket, buckets, queue, mid_blocks, lanes, B, S, T);
 }
 void l_reduce_segments(hipStream_t st, const uint32_t* buckets, int W, uint32_t B, uint32_t L, uint32_t* out) {
     hipLaunchKernelGGL(k_reduce_segments, dim3(blocks_for((size_t)W * (B / L) * RED_LANES, 64)), dim3(64), 0, st, buckets, W, B,

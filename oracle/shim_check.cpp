@@ -180,6 +180,63 @@ static void check_headline_size()
     }
 }
 
+// Small-input routing (libff_amd::small_input_threshold): every n from 1 to 64 through the routed libff::multi_exp with
+// the threshold at 0 (the device takes every size) and above n (the caller's own libff body runs, reached through the
+// field tag type: multiexp.tcc:655-661 is what the reference does with such inputs), both against naive_plain; the
+// same for multi_exp_filter_one_zero and for a direct call of the inner class.  Prints the per-call times of the two
+// routes, which is where the default threshold comes from.
+static bool cpu_route_only = false;   // --cpu-route-only: no device in this process (the CPU test suite)
+template<typename G, typename Fr> void check_small_routing(const char *name)
+{
+    const size_t saved = libff_amd::small_input_threshold();
+    bool ok = true;
+    double t_dev[4] = {0, 0, 0, 0}, t_cpu[4] = {0, 0, 0, 0};
+    const size_t marks[4] = {4, 16, 32, 64};
+    for (size_t n = 1; n <= 64; ++n) {
+        std::vector<G> bases;
+        std::vector<Fr> scalars;
+        G cur = Fr(3) * G::one();
+        for (size_t i = 0; i < n; ++i) {
+            bases.push_back(cur);
+            cur = cur + G::one();
+            scalars.push_back(SHA512_rng<Fr>(40000 + 100 * n + i));
+        }
+        if (n > 2) {
+            scalars[n - 1] = Fr::one();
+            scalars[n / 2] = Fr::zero();
+        }
+        const G expect = multi_exp<G, Fr, multi_exp_method_naive_plain>(
+            bases.cbegin(), bases.cend(), scalars.cbegin(), scalars.cend(), 1);
+        for (int route = cpu_route_only ? 1 : 0; route < 2; ++route) {
+            libff_amd::small_input_threshold() = route ? 1000 : 0;
+            const auto t0 = std::chrono::steady_clock::now();
+            const G a = multi_exp<G, Fr, multi_exp_method_BDLO12_signed, multi_exp_base_form_normal>(
+                bases.cbegin(), bases.cend(), scalars.cbegin(), scalars.cend(), 1);
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            const G b = multi_exp<G, Fr, multi_exp_method_BDLO12>(
+                bases.cbegin(), bases.cend(), scalars.cbegin(), scalars.cend(), 2);
+            // (the reference prints three statistics lines per call: a few sizes only)
+            const G c = (n == 1 || n == 5 || n == 33 || n == 64)
+                            ? multi_exp_filter_one_zero<G, Fr, multi_exp_method_BDLO12_signed, multi_exp_base_form_normal>(
+                                  bases.cbegin(), bases.cend(), scalars.cbegin(), scalars.cend(), 1)
+                            : expect;
+            const G d = internal::multi_exp_implementation<G, Fr, multi_exp_method_BDLO12_signed, multi_exp_base_form_normal>::
+                multi_exp_inner(bases.cbegin(), bases.cend(), scalars.cbegin(), scalars.cend());
+            ok = ok && (expect == a) && (expect == b) && (expect == c) && (expect == d);
+            for (int m = 0; m < 4; ++m) {
+                if (n == marks[m]) (route ? t_cpu : t_dev)[m] = ms;
+            }
+        }
+    }
+    libff_amd::small_input_threshold() = saved;
+    printf("%-14s small-input routing n=1..64: %s   one call, device / caller's libff (ms): n=4 %.3f / %.3f  n=16 %.3f / %.3f  "
+           "n=32 %.3f / %.3f  n=64 %.3f / %.3f\n", name, ok ? "ok" : "MISMATCH", t_dev[0], t_cpu[0], t_dev[1], t_cpu[1],
+           t_dev[2], t_cpu[2], t_dev[3], t_cpu[3]);
+    if (!ok) {
+        ++failures;
+    }
+}
+
 // libff_amd::multi_exp_batch: three (bases, scalars) pairs as one batch == the three single multi_exp calls
 template<typename G, typename Fr> void check_batch(const char *name, size_t n)
 {
@@ -210,8 +267,9 @@ template<typename G, typename Fr> void check_batch(const char *name, size_t n)
     }
 }
 
-int main()
+int main(int argc, char **argv)
 {
+    cpu_route_only = argc > 1 && std::string(argv[1]) == "--cpu-route-only";
     // SHIM_CHECK_MIN_SPLIT=<points>: with AMDMSM_DEVICES="0,0" (two contexts on one GPU) even the
     // small cases below take the multi-device route (amdmsm_multi_exp_multi)
     if (const char *ms = std::getenv("SHIM_CHECK_MIN_SPLIT")) {
@@ -229,6 +287,16 @@ int main()
     bls12_377_pp::init_public_params();
     bw6_761_pp::init_public_params();
     bls12_381_pp::init_public_params();
+    printf("small-input threshold (default / AMDMSM_CPU_BELOW): %zu\n", libff_amd::small_input_threshold());
+    check_small_routing<alt_bn128_G1, alt_bn128_Fr>("alt_bn128_G1");
+    check_small_routing<bls12_377_G2, bls12_377_Fr>("bls12_377_G2");
+    check_small_routing<bw6_761_G1, bw6_761_Fr>("bw6_761_G1");
+    if (cpu_route_only) {
+        printf(failures ? "SHIM CHECK FAILED (%d)\n" : "SHIM CPU ROUTE PASSED\n", failures);
+        return failures ? 1 : 0;
+    }
+    // everything below goes to the device whatever its size: the small cases of check_group are device tests
+    libff_amd::small_input_threshold() = 0;
     check_group<alt_bn128_G1, alt_bn128_Fr>("alt_bn128_G1", {1, 2, 5, 257, 4096});
     check_group<alt_bn128_G2, alt_bn128_Fr>("alt_bn128_G2", {1, 5, 600});
     check_group<bls12_377_G1, bls12_377_Fr>("bls12_377_G1", {1, 5, 1500});

@@ -63,3 +63,17 @@ def test_shim_header_compiles_against_reference():
            "-DMONTGOMERY_OUTPUT", "-DUSE_ASM", "-w", "-I" + ref, "-I" + gmpinc, "-I" + os.path.join(ROOT, "include"), src]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
+
+
+def test_shim_small_inputs_run_the_callers_libff_without_a_device():
+    """Below libff_amd::small_input_threshold() the routed libff::multi_exp runs the reference's own generic body in the
+    caller's translation unit (multiexp.tcc:655-661 is what the reference does with a handful of points): n = 1 .. 64 for
+    three groups against naive_plain, in a process that never touches a GPU.  Needs the binary built against the
+    reference, i.e. this container."""
+    import torch
+
+    if not os.path.exists(BIN) or torch.cuda.is_available():
+        pytest.skip("oracle/_ref/shim_check not built, or a GPU box (the device tests above cover both routes there)")
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+    r = subprocess.run([BIN, "--cpu-route-only"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and "SHIM CPU ROUTE PASSED" in r.stdout and r.stdout.count("routing n=1..64: ok") == 3, r.stdout[-2000:]
