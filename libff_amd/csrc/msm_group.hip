@@ -1079,6 +1079,106 @@ template <class T> AMDMSM_DEV void load_xyzz_rec(Xyzz<T>& p, const uint32_t* q) 
 template <class T> AMDMSM_DEV void store_xyzz_rec(uint32_t* q, const Xyzz<T>& p) { store_xyzz(q, p); }
 #endif
 
+// Running sum of records for the serial parts of the fix-up kernels and of k_bucket_sums: on reduced-radix limbs where
+// k_accumulate writes them (rr.cuh xyzz_add_rho: every coordinate with the factor rho, 2 L^2 multiply issues per product,
+// no carry instructions), on canonical words otherwise.  rec_sum_get hands the sum over as canonical words for the
+// wave-level butterflies, which stay on fp.cuh's arithmetic.
+#ifndef AMDMSM_SUM_RR
+#define AMDMSM_SUM_RR AMDMSM_ACC_RR
+#endif
+#if AMDMSM_SUM_RR
+struct rec_sum {
+    XyzzRr<ERR> a;
+    bool inf;
+};
+AMDMSM_DEV void rec_sum_init(rec_sum& s) {
+    s.inf = true;
+    re_zero(s.a.x); re_zero(s.a.y); re_zero(s.a.zz); re_zero(s.a.zzz);   // (the fold moves the limbs of infinite lanes too)
+}
+// the record at q on limbs, all four coordinates with the factor rho; inf: the record is the point at infinity
+AMDMSM_DEV void rec_load_rho(XyzzRr<ERR>& p, bool& inf, const uint32_t* q) {
+    const uint32_t mk = q[ZZS - 1];
+    if (((mk ^ (mk << 1)) >> 31) != 0) {   // canonical words (a fix-up kernel's sum): one product per coordinate
+        Xyzz<ER> c;
+        load_xyzz(c, q);
+        inf = xyzz_is_inf(c);
+        re_from_words_rho(p.x, lane_words(c.x));
+        re_from_words_rho(p.y, lane_words(c.y));
+        re_from_words_rho(p.zz, lane_words(c.zz));
+        re_from_words_rho(p.zzz, lane_words(c.zzz));
+        return;
+    }
+    const uint4* q4 = reinterpret_cast<const uint4*>(q + (GP::DEG == 2 && (threadIdx.x & 1u) ? 4 * RRL : 0));
+    uint32_t any = 0;
+#pragma unroll
+    for (int k = 0; k < RRL; ++k) {
+        const uint4 v = q4[k];
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = 4 * k + j;   // limb i % L of coordinate i / L
+            int32_t& dst = i < RRL ? re_limb(p.x, i) : (i < 2 * RRL ? re_limb(p.y, i - RRL) : (i < 3 * RRL ? re_limb(p.zz, i - 2 * RRL) : re_limb(p.zzz, i - 3 * RRL)));
+            dst = (int32_t)w[j];
+            if (i >= 2 * RRL && i < 3 * RRL) any |= w[j];
+        }
+    }
+    // k_accumulate writes infinity as an all-zero record; the zz of a finite point is never zero mod p, let alone on limbs
+    inf = re_all<ERR>(any == 0);
+    xyzz_rec_to_rho(p);
+}
+AMDMSM_DEV void rec_sum_add(rec_sum& s, const uint32_t* q) {
+    XyzzRr<ERR> b;
+    bool b_inf;
+    rec_load_rho(b, b_inf, q);
+    xyzz_add_rho(s.a, s.inf, b, b_inf);
+}
+// the sums of G neighbouring reduction lanes (a reduction lane is RED_LANES physical lanes wide) folded into the first
+// of them: XOR butterfly on limbs, infinity outside the data; every lane of the wave must call it
+AMDMSM_DEV void rec_sum_fold(rec_sum& s, uint32_t G) {
+    for (uint32_t off = 1; off < G; off <<= 1) {
+        XyzzRr<ERR> o;
+        const int m = (int)(off * RED_LANES);
+#pragma unroll
+        for (int i = 0; i < RRL; ++i) {
+            re_limb(o.x, i) = __shfl_xor(re_limb(s.a.x, i), m, 64);
+            re_limb(o.y, i) = __shfl_xor(re_limb(s.a.y, i), m, 64);
+            re_limb(o.zz, i) = __shfl_xor(re_limb(s.a.zz, i), m, 64);
+            re_limb(o.zzz, i) = __shfl_xor(re_limb(s.a.zzz, i), m, 64);
+        }
+        const bool o_inf = __shfl_xor(s.inf ? 1 : 0, m, 64) != 0;
+        xyzz_add_rho(s.a, s.inf, o, o_inf);
+    }
+}
+AMDMSM_DEV void rec_sum_get(Xyzz<ER>& out, const rec_sum& s) {
+    if (s.inf) {
+        xyzz_set_inf(out);
+        return;
+    }
+    rr_export_component<FQ, 0>(lane_words(out.x), re_comp(s.a.x));
+    rr_export_component<FQ, 0>(lane_words(out.y), re_comp(s.a.y));
+    rr_export_component<FQ, 0>(lane_words(out.zz), re_comp(s.a.zz));
+    rr_export_component<FQ, 0>(lane_words(out.zzz), re_comp(s.a.zzz));
+}
+#else
+struct rec_sum {
+    Xyzz<ER> a;
+};
+AMDMSM_DEV void rec_sum_init(rec_sum& s) { xyzz_set_inf(s.a); }
+AMDMSM_DEV void rec_sum_add(rec_sum& s, const uint32_t* q) {
+    Xyzz<ER> x;
+    load_xyzz_rec(x, q);
+    xyzz_add(s.a, s.a, x);
+}
+AMDMSM_DEV void rec_sum_get(Xyzz<ER>& out, const rec_sum& s) { out = s.a; }
+AMDMSM_DEV void wave_group_sum_r(Jac<ER>& p, uint32_t G);
+AMDMSM_DEV void rec_sum_fold(rec_sum& s, uint32_t G) {
+    Jac<ER> j;
+    xyzz_to_jac(j, s.a);
+    wave_group_sum_r(j, G);
+    jac_to_xyzz(s.a, j);
+}
+#endif
+
 // smallest b with e[b] > k   (e non-decreasing, e[B-1] > k)
 AMDMSM_DEV uint32_t bucket_of_entry(const uint32_t* __restrict__ e, uint32_t B, uint32_t k) {
     uint32_t l = 0, r = B - 1;
@@ -1354,16 +1454,16 @@ __global__ void __launch_bounds__(64) k_accumulate_fixup(const uint32_t* __restr
         }
     }
     if (span == 0 || span > INLINE_SPAN) return;
-    Xyzz<ER> acc, x;
-    load_xyzz_rec(acc, part_last + g * ZZS);
+    rec_sum sum;
+    rec_sum_init(sum);
+    rec_sum_add(sum, part_last + g * ZZS);
 #ifndef AMDMSM_FIX_PRIO
 #define AMDMSM_FIX_PRIO 1
 #endif
     // priority falling with progress, as in k_accumulate: the waves of a SIMD end together
     if (AMDMSM_FIX_PRIO) __builtin_amdgcn_s_setprio(3);
     for (uint32_t u = t + 1; u <= t_last; ++u) {
-        load_xyzz_rec(x, part_first + (w * T + u) * ZZS);
-        xyzz_add(acc, acc, x);
+        rec_sum_add(sum, part_first + (w * T + u) * ZZS);
         if (AMDMSM_FIX_PRIO) {
             const uint32_t done = (uint32_t)__builtin_amdgcn_readfirstlane((int)(u - t));
             if (done == 1) __builtin_amdgcn_s_setprio(2);
@@ -1371,6 +1471,8 @@ __global__ void __launch_bounds__(64) k_accumulate_fixup(const uint32_t* __restr
             if (done >= 3) __builtin_amdgcn_s_setprio(0);
         }
     }
+    Xyzz<ER> acc;
+    rec_sum_get(acc, sum);
     store_xyzz_rec(buckets + (w * B + b) * ZZS, acc);
 }
 
@@ -1395,16 +1497,12 @@ AMDMSM_DEV void fixup_compact_block(uint32_t blk, const uint32_t* __restrict__ e
     // the bucket of the last entry before the block still runs in the block's last lane
     if (bucket_of_entry(e, B, (uint32_t)ent_a) != bucket_of_entry(e, B, (uint32_t)ent_b)) return;
     const uint32_t lane = (threadIdx.x & 63u) / RED_LANES;   // reduction lane of the wave, RED_FOLD of them
-    Xyzz<ER> acc, x;
-    xyzz_set_inf(acc);
-    for (uint32_t u = first + lane; u <= last; u += RED_FOLD) {
-        load_xyzz_rec(x, part_first + (w * T + u) * ZZS);
-        xyzz_add(acc, acc, x);
-    }
-    Jac<ER> j;
-    xyzz_to_jac(j, acc);
-    wave_group_sum_r(j, RED_FOLD);
-    jac_to_xyzz(acc, j);
+    rec_sum sum;
+    rec_sum_init(sum);
+    for (uint32_t u = first + lane; u <= last; u += RED_FOLD) rec_sum_add(sum, part_first + (w * T + u) * ZZS);
+    rec_sum_fold(sum, RED_FOLD);
+    Xyzz<ER> acc;
+    rec_sum_get(acc, sum);
     if (lane == 0) store_xyzz_rec(part_first + (w * T + first) * ZZS, acc);
 }
 
@@ -1437,8 +1535,8 @@ __global__ void __launch_bounds__(64, AMDMSM_TAIL_WAVES) k_accumulate_fixup_queu
     for (uint32_t q0 = bid * per_wave; q0 < count; q0 += nblk * per_wave) {
         const uint32_t q = q0 + sub;
         const bool live = q < count;
-        Xyzz<ER> acc, x;
-        xyzz_set_inf(acc);
+        rec_sum sum;
+        rec_sum_init(sum);
         size_t w = 0;
         uint32_t b = 0;
         if (live) {
@@ -1447,7 +1545,7 @@ __global__ void __launch_bounds__(64, AMDMSM_TAIL_WAVES) k_accumulate_fixup_queu
             const uint32_t t = (uint32_t)(g % T);
             b = cont_bucket[g];
             const uint32_t t_last = (ends[w * B + b] - 1) / S;
-            if (lane == 0) load_xyzz_rec(acc, part_last + g * ZZS);
+            if (lane == 0) rec_sum_add(sum, part_last + g * ZZS);
             // lanes t+1 .. t_last = head [t+1, h), nb folded blocks from h, tail [tail0, t_last]
             uint32_t h = (t + 1 + FIX_BLOCK - 1) / FIX_BLOCK * FIX_BLOCK;
             uint32_t nb = 0;
@@ -1456,14 +1554,12 @@ __global__ void __launch_bounds__(64, AMDMSM_TAIL_WAVES) k_accumulate_fixup_queu
             const uint32_t items = nh + nb + (t_last + 1 - tail0);
             for (uint32_t i = lane; i < items; i += G) {
                 const uint32_t u = i < nh ? t + 1 + i : (i < nh + nb ? h + (i - nh) * FIX_BLOCK : tail0 + (i - nh - nb));
-                load_xyzz_rec(x, part_first + (w * T + u) * ZZS);
-                xyzz_add(acc, acc, x);
+                rec_sum_add(sum, part_first + (w * T + u) * ZZS);
             }
         }
-        Jac<ER> j;
-        xyzz_to_jac(j, acc);
-        wave_group_sum_r(j, G);
-        jac_to_xyzz(acc, j);
+        rec_sum_fold(sum, G);
+        Xyzz<ER> acc;
+        rec_sum_get(acc, sum);
         if (live && lane == 0) store_xyzz_rec(buckets + (w * B + b) * ZZS, acc);
     }
 }
@@ -1651,22 +1747,21 @@ __global__ void __launch_bounds__(64, AMDMSM_TAIL_WAVES) k_bucket_sums(const uin
     const size_t w = t / per_w;
     const uint32_t rem = (uint32_t)(t % per_w), o = rem / g, j = rem % g;
     const bool valid = w < (size_t)W;
-    Xyzz<ER> xa, xb;
-    xyzz_set_inf(xa);
+    rec_sum sum;
+    rec_sum_init(sum);
     if (valid) {
         const uint32_t* bk = buckets + w * (size_t)B * ZZS;
         for (uint32_t i = 0; i < q; ++i) {
             const uint32_t idx = j * q + i;
             const uint64_t b1 = col ? (uint64_t)idx * C + o : (uint64_t)o * C + idx;   // weight b + 1
-            if (b1 >= 1 && b1 <= B) {
-                load_xyzz_rec(xb, bk + (size_t)(b1 - 1) * ZZS);
-                xyzz_add(xa, xa, xb);
-            }
+            if (b1 >= 1 && b1 <= B) rec_sum_add(sum, bk + (size_t)(b1 - 1) * ZZS);
         }
     }
+    rec_sum_fold(sum, g);
+    Xyzz<ER> xa;
+    rec_sum_get(xa, sum);
     Jac<ER> p;
     xyzz_to_jac(p, xa);
-    wave_group_sum_r(p, g);
     if (valid && j == 0) store_jac(out + (w * (size_t)(R + 1 + C) + (col ? R + 1 + o : o)) * XYZW, p);
 }
 

@@ -744,6 +744,104 @@ AMDMSM_DEV void xyzz_madd_rr(XyzzRr<E>& acc, bool& inf, const uint32_t (&wx)[N],
     xyzz_madd_rr(acc, inf, wx, wy, neg, [] {});
 }
 
+// ---- general XYZZ addition, every coordinate with the factor rho (bucket reduction, fix-up) -----------------------
+// The serial sums of k_bucket_sums and of the fix-up kernels (multiexp_accumulate_buckets, multiexp.tcc:90-125, as plain
+// sums) add records k_accumulate left on limbs; on limbs they stay, at 2 L^2 multiply issues per product instead of the
+// 4 N^2 multiply + carry pairs of fp.cuh.  add-2008-s needs one common factor on all four coordinates (X3 = R^2 - PPP - 2Q
+// mixes a square of S-terms with a cube of U-terms), so a record's zz / zzz are first brought from rho 2^D to rho
+// (xyzz_rec_to_rho: a product by 2^(32N) with a one-limb factor, half a product each).
+template <class P> AMDMSM_DEV Rr<P>& re_comp(Rr<P>& a) { return a; }
+template <class P, int NR> AMDMSM_DEV Rr<P>& re_comp(Rr2H<P, NR>& a) { return a.h; }
+template <class P> AMDMSM_DEV const Rr<P>& re_comp(const Rr<P>& a) { return a; }
+template <class P, int NR> AMDMSM_DEV const Rr<P>& re_comp(const Rr2H<P, NR>& a) { return a.h; }
+
+template <class P, int E>
+AMDMSM_DEV void rr_mul_pow2(Rr<P>& r, const Rr<P>& a);
+
+// zz, zzz of a record as k_accumulate stores it (factor rho 2^D) -> factor rho
+template <class E>
+AMDMSM_DEV void xyzz_rec_to_rho(XyzzRr<E>& p) {
+    using P = typename re_info<E>::params;
+    rr_mul_pow2<P, 32 * P::N>(re_comp(p.zz), re_comp(p.zz));
+    rr_mul_pow2<P, 32 * P::N>(re_comp(p.zzz), re_comp(p.zzz));
+}
+
+// a = 2 a (dbl-2008-s-1 with a = 0, as xyzz_dbl in ec.cuh); a point of order two (y == 0) doubles to infinity
+template <class E>
+AMDMSM_DEV void xyzz_dbl_rho(XyzzRr<E>& a, bool& inf) {
+    using P = typename re_info<E>::params;
+    if (inf) return;
+    // (y of a record copied into the sum may still be a first point's: below 2^D p)
+    if (re_maybe_zero<rr_filter_k<P>()>(a.y) && re_is_zero_exact(a.y)) {
+        inf = true;
+        return;
+    }
+    E u, v, w, s, m, t, c, x1, y1;
+    // x, y of a copied record may be as large as 2^D p: one product by one each brings them below 2 p, so that the
+    // doubled point's coordinates stay within what the export of a sum assumes (tests/test_rr_bounds.py); this path
+    // is rare (equal sums meet)
+    constexpr int BL = rr_shape<P>::B * rr_shape<P>::L;
+    re_set_pow2<BL>(c);
+    re_mul(x1, a.x, c);
+    re_mul(y1, a.y, c);
+    re_small_times(u, y1, 2);      // U = 2 Y1
+    re_sqr(v, u);                  // V = U^2
+    re_mul(w, u, v);               // W = U V
+    re_mul(s, x1, v);              // S = X1 V
+    re_sqr(t, x1);
+    re_small_times(m, t, 3);       // M = 3 X1^2
+    re_sqr(t, m);
+    re_small_times(c, s, 2);
+    re_sub(t, t, c);
+    re_norm(a.x, t);               // X3 = M^2 - 2S
+    re_sub(s, s, a.x);
+    re_mul_sub_mul(t, m, s, w, y1);   // Y3 = M (S - X3) - W Y1
+    a.y = t;
+    re_mul(a.zz, v, a.zz);
+    re_mul(a.zzz, w, a.zzz);
+}
+
+// a += b (add-2008-s with the special cases of G::add: infinity on either side, equal points -> doubling, opposite
+// points -> infinity; e.g. alt_bn128_g1.cpp:151-206), as xyzz_add in ec.cuh
+template <class E>
+AMDMSM_DEV void xyzz_add_rho(XyzzRr<E>& a, bool& a_inf, const XyzzRr<E>& b, bool b_inf) {
+    using P = typename re_info<E>::params;
+    constexpr int L = rr_shape<P>::L;
+    if (b_inf) return;
+    if (a_inf) {
+        a = b;
+        a_inf = false;
+        return;
+    }
+    E u1, s1, pp, r, ppp, q, t;
+    re_mul(u1, a.x, b.zz);
+    re_mul(pp, b.x, a.zz);
+    re_mul(s1, a.y, b.zzz);
+    re_mul(r, b.y, a.zzz);
+    re_sub(pp, pp, u1);            // P = U2 - U1
+    re_sub(r, r, s1);              // R = S2 - S1
+    if (__builtin_expect(re_maybe_zero<64>(pp), 0)) {
+        if (re_is_zero_exact(pp)) {
+            if (re_is_zero_exact(r)) xyzz_dbl_rho(a, a_inf);
+            else a_inf = true;
+            return;
+        }
+    }
+    re_sqr(ppp, pp);               // PP
+    re_mul(q, u1, ppp);            // Q = U1 PP
+    re_mul(t, a.zz, b.zz);
+    re_mul(a.zz, t, ppp);          // ZZ3 = ZZ1 ZZ2 PP
+    re_mul(ppp, pp, ppp);          // PPP
+    re_mul(t, a.zzz, b.zzz);
+    re_mul(a.zzz, t, ppp);         // ZZZ3 = ZZZ1 ZZZ2 PPP
+    re_sqr(t, r);
+#pragma unroll
+    for (int i = 0; i < L; ++i) re_limb(t, i) = re_limb(t, i) - re_limb(ppp, i) - 2 * re_limb(q, i);   // X3 = R^2 - PPP - 2Q
+    re_norm(a.x, t);
+    re_sub(q, q, a.x);
+    re_mul_sub_mul(a.y, r, q, s1, ppp);   // Y3 = R (Q - X3) - S1 PPP
+}
+
 // r = a * 2^E / rho: the product scan with a one-limb second factor -- one multiply per column in the multiplication
 // half instead of up to L (k_rr_export runs four of these per record)
 template <class P, int E, int K>

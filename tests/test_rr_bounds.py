@@ -345,3 +345,96 @@ def test_jacobian_chain_bounds(name):
     for step in range(8):    # an addition behind every doubling
         p = madd_j(dbl(p))
     assert ch.worst_column < 2 ** 63
+
+
+# ---- general XYZZ addition on limbs (rr.cuh xyzz_add_rho / xyzz_dbl_rho: k_bucket_sums and the fix-up kernels) ----
+def pow2_32n(ch):
+    """the one-limb factor 2^(32N) of rr_mul_pow2<P, 32N> as an element: value rho / (2^D p) in units of p"""
+    s = ch.s
+    v = 1.0 / (s.ratio * 2 ** s.D)
+    return El(0, 2 ** s.B - 1, 0, 2 ** s.B - 1, 0, v, v)
+
+
+def rec_to_rho(ch, rec):
+    """rec_load_rho on a limb record: x, y as stored, zz / zzz times 2^(32N) / rho (xyzz_rec_to_rho)"""
+    c = pow2_32n(ch)
+    return dict(x=rec["x"], y=rec["y"], zz=ch.product([(ch.factor_ok(rec["zz"]), c)]), zzz=ch.product([(ch.factor_ok(rec["zzz"]), c)]))
+
+
+def canonical_to_rho(ch, fq2_nr=0):
+    """rec_load_rho on a canonical record: one product by rho 2^D mod p per coordinate (re_from_words_rho)"""
+    mul, _, _ = ops(ch, fq2_nr)
+    e = mul(canonical(ch), one_el(ch))
+    return dict(x=e, y=e, zz=e, zzz=e)
+
+
+def dbl_rho(ch, a, fq2_nr=0):
+    mul, sqr, mul_sub_mul = ops(ch, fq2_nr)
+    assert a["y"].val < 2 ** ch.s.D + 64   # rr_filter_k: the bound of the y == 0 filter
+    x1, y1 = mul(a["x"], one_el(ch)), mul(a["y"], one_el(ch))   # contracted copies
+    u = ch.small_times(y1, 2)
+    v = sqr(u)
+    w = mul(u, v)
+    sv = mul(x1, v)
+    m = ch.small_times(sqr(x1), 3)
+    t = sqr(m)
+    x3 = ch.norm(ch.lin([(1, t), (-1, ch.small_times(sv, 2))]))
+    y3 = mul_sub_mul(m, ch.lin([(1, sv), (-1, x3)]), w, y1)
+    return dict(x=x3, y=y3, zz=mul(v, a["zz"]), zzz=mul(w, a["zzz"]))
+
+
+def add_rho(ch, a, b, fq2_nr=0):
+    mul, sqr, mul_sub_mul = ops(ch, fq2_nr)
+    u1 = mul(a["x"], b["zz"])
+    pp = ch.lin([(1, mul(b["x"], a["zz"])), (-1, u1)])
+    s1 = mul(a["y"], b["zzz"])
+    r = ch.lin([(1, mul(b["y"], a["zzz"])), (-1, s1)])
+    assert pp.val < 64, f"|P| = {pp.val} p exceeds the filter bound"
+    ppp = sqr(pp)
+    q = mul(u1, ppp)
+    zz = mul(mul(a["zz"], b["zz"]), ppp)
+    ppp = mul(pp, ppp)
+    zzz = mul(mul(a["zzz"], b["zzz"]), ppp)
+    x3 = ch.norm(ch.lin([(1, sqr(r)), (-1, ppp), (-2, q)]))
+    y3 = mul_sub_mul(r, ch.lin([(1, q), (-1, x3)]), s1, ppp)
+    return dict(x=x3, y=y3, zz=zz, zzz=zzz)
+
+
+def general_add_states(ch, fq2_nr=0):
+    """every operand the serial sums can meet: records in any state of the bucket loop (brought to the factor rho),
+    canonical records, and sums of any number of them (incl. the doubling of a sum)"""
+    records = []
+    for start in (first_point(ch, fq2_nr), doubling_path(ch, fq2_nr)):
+        acc = start
+        for _ in range(5):
+            records.append(rec_to_rho(ch, acc))
+            acc = madd(ch, acc, fq2_nr=fq2_nr)
+    records.append(canonical_to_rho(ch, fq2_nr))
+    rec = records[0]
+    for r in records[1:]:
+        rec = widen(rec, r)
+    s = ch.s
+    # what the export of a sum (rec_sum_get: a 2^(32N) / rho in (-p, 2p)) and of a copied record needs
+    assert rec["x"].val <= 2 ** s.D and rec["y"].val <= 2 ** s.D, rec
+    acc = rec
+    for _ in range(6):
+        nxt = widen(add_rho(ch, acc, rec, fq2_nr), dbl_rho(ch, acc, fq2_nr))
+        nxt = widen(nxt, add_rho(ch, acc, acc, fq2_nr))   # two sums (the row / column lanes add records only, the check is free)
+        acc = widen(acc, nxt)
+        for k in ("x", "y", "zz", "zzz"):
+            assert acc[k].val <= 2 ** s.D, (k, acc[k])
+    return acc
+
+
+@pytest.mark.parametrize("name", list(MODULI))
+def test_general_add_bounds_fq(name):
+    ch = Checker(Shape(name))
+    general_add_states(ch)
+    assert ch.worst_column < 2 ** 63
+
+
+@pytest.mark.parametrize("name", list(FQ2_NR))
+def test_general_add_bounds_fq2(name):
+    ch = Checker(Shape(name))
+    general_add_states(ch, fq2_nr=FQ2_NR[name])
+    assert ch.worst_column < 2 ** 63

@@ -171,6 +171,111 @@ __global__ void __launch_bounds__(256) k_check_jac(const uint32_t* __restrict__ 
     for (int j = 0; j < N; ++j) { outrr[i * 2 * N + j] = rb.x.v[j]; outrr[i * 2 * N + N + j] = rb.y.v[j]; }
 }
 
+
+template <class P, bool I> __device__ __forceinline__ uint32_t (&lane_words32(Fp<P, I>& a))[P::N] { return a.v; }
+template <class P, int NR> __device__ __forceinline__ uint32_t (&lane_words32(Fp2H<P, NR>& a))[P::N] { return a.h.v; }
+
+// General XYZZ additions on limbs (rr.cuh xyzz_add_rho / xyzz_dbl_rho: the serial sums of k_bucket_sums and the fix-up
+// kernels) against xyzz_add on 32-bit words.  Each lane builds two bucket accumulators A and B by mixed additions
+// (0 .. 3 points each: infinity, a first point's form, general sums), both ways, then computes (A + B) + A and A + A;
+// lane % 8 == 1: B == A (doubling), 2: B == -A (infinity), 3: B from canonical words (a fix-up kernel's record).
+// T32 / TRR: Fp<P> / Rr<P>, or Fp2H / Rr2H on lane pairs (comp = this thread's component).
+template <class P, class T32, class TRR, int LANES>
+__global__ void __launch_bounds__(256) k_check_add(const uint32_t* __restrict__ pts, size_t npts, int len, uint32_t* out32,
+                                                   uint32_t* outrr) {
+    constexpr int N = P::N;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t i = t / LANES;
+    const uint32_t comp = (uint32_t)(t % LANES);
+    const int mode = (int)(i % 8);
+    Xyzz<T32> a[2];
+    XyzzRr<TRR> b[2];
+    bool inf[2] = {true, true};
+    for (int h = 0; h < 2; ++h) {
+        xyzz_set_inf(a[h]);
+        re_zero(b[h].x); re_zero(b[h].y); re_zero(b[h].zz); re_zero(b[h].zzz);
+        const int cnt = h == 0 ? (int)(i / 8 % 4) % (len + 1) : (int)(i / 32 % 4) % (len + 1);
+        for (int k = 0; k < cnt; ++k) {
+            size_t idx = (i * 131 + (size_t)k * 7 + (size_t)h * 1009) % npts;
+            bool neg = ((i + k) & 1) != 0;
+            if (h == 1 && (mode == 1 || mode == 2)) {   // the same points as A, or their negatives
+                idx = (i * 131 + (size_t)k * 7) % npts;
+                if (mode == 2) neg = !neg;
+            }
+            const uint32_t* rec = LANES == 2 ? pts + (idx / 2) * 4 * N : pts + idx * 2 * N;
+            uint32_t wx[N], wy[N];
+            for (int j = 0; j < N; ++j) { wx[j] = rec[comp * N + j]; wy[j] = rec[LANES * N + comp * N + j]; }
+            Aff<T32> p;
+            for (int j = 0; j < N; ++j) { lane_words32(p.x)[j] = wx[j]; lane_words32(p.y)[j] = wy[j]; }
+            el_cneg(p.y, p.y, neg);
+            xyzz_madd_lz(a[h], p);
+            xyzz_madd_rr(b[h], inf[h], wx, wy, neg);
+        }
+        xyzz_canon(a[h]);
+        if (h == 1 && (mode == 1 || mode == 2)) {   // same count as A
+            // (cnt of B may differ from A's: rebuild B from A's own state instead)
+        }
+    }
+    if (mode == 1 || mode == 2) {   // B := +-A exactly, whatever the counts
+        a[1] = a[0];
+        b[1] = b[0];
+        inf[1] = inf[0];
+        if (mode == 2) {
+            el_neg(a[1].y, a[1].y);
+            re_neg(b[1].y, b[1].y);
+            re_norm(b[1].y, b[1].y);
+        }
+    }
+    // 32-bit: s = (A + B) + A, d = A + A
+    Xyzz<T32> s32, d32;
+    xyzz_add(s32, a[0], a[1]);
+    xyzz_add(s32, s32, a[0]);
+    xyzz_add(d32, a[0], a[0]);
+    // limbs: records -> factor rho (B through canonical words in mode 3), then the same sums
+    XyzzRr<TRR> ra = b[0], rb = b[1];
+    bool ia = inf[0], ib = inf[1];
+    if (ia) { re_zero(ra.x); re_zero(ra.y); re_zero(ra.zz); re_zero(ra.zzz); }
+    if (ib) { re_zero(rb.x); re_zero(rb.y); re_zero(rb.zz); re_zero(rb.zzz); }
+    xyzz_rec_to_rho(ra);
+    if (mode == 3) {
+        re_from_words_rho(rb.x, lane_words32(a[1].x));
+        re_from_words_rho(rb.y, lane_words32(a[1].y));
+        re_from_words_rho(rb.zz, lane_words32(a[1].zz));
+        re_from_words_rho(rb.zzz, lane_words32(a[1].zzz));
+    } else {
+        xyzz_rec_to_rho(rb);
+    }
+    XyzzRr<TRR> srr = ra, drr = ra;
+    bool is = ia, id = ia;
+    xyzz_add_rho(srr, is, rb, ib);
+    xyzz_add_rho(srr, is, ra, ia);
+    xyzz_add_rho(drr, id, ra, ia);
+    auto put32 = [&](uint32_t* o, const Xyzz<T32>& v) {
+        const bool z = xyzz_is_inf(v);
+        for (int j = 0; j < N; ++j) {
+            o[j] = z ? 0u : lane_words32(const_cast<Xyzz<T32>&>(v).x)[j];
+            o[N + j] = z ? 0u : lane_words32(const_cast<Xyzz<T32>&>(v).y)[j];
+            o[2 * N + j] = z ? 0u : lane_words32(const_cast<Xyzz<T32>&>(v).zz)[j];
+            o[3 * N + j] = z ? 0u : lane_words32(const_cast<Xyzz<T32>&>(v).zzz)[j];
+        }
+    };
+    auto putrr = [&](uint32_t* o, const XyzzRr<TRR>& v, bool z) {
+        uint32_t w[N];
+        rr_export_component<P, 0>(w, re_comp(v.x));
+        for (int j = 0; j < N; ++j) o[j] = z ? 0u : w[j];
+        rr_export_component<P, 0>(w, re_comp(v.y));
+        for (int j = 0; j < N; ++j) o[N + j] = z ? 0u : w[j];
+        rr_export_component<P, 0>(w, re_comp(v.zz));
+        for (int j = 0; j < N; ++j) o[2 * N + j] = z ? 0u : w[j];
+        rr_export_component<P, 0>(w, re_comp(v.zzz));
+        for (int j = 0; j < N; ++j) o[3 * N + j] = z ? 0u : w[j];
+    };
+    put32(out32 + t * 8 * N, s32);
+    put32(out32 + t * 8 * N + 4 * N, d32);
+    putrr(outrr + t * 8 * N, srr, is);
+    putrr(outrr + t * 8 * N + 4 * N, drr, id);
+}
+
 template <class P, int WAVES>
 __global__ void __launch_bounds__(256, WAVES) k_time32(const uint32_t* __restrict__ pts, size_t npts, int len, uint32_t* out) {
     constexpr int N = P::N;
@@ -303,6 +408,42 @@ int run(const char* name) {
         }
         printf("%s, Jacobian chains: len %2d: %d mismatches of %zu lanes\n", name, len, mism, lanes);
         bad += mism;
+    }
+    {   // general additions on limbs against xyzz_add
+        uint32_t *a32, *arr;
+        hipMalloc(&a32, lanes * 8 * N * 4);
+        hipMalloc(&arr, lanes * 8 * N * 4);
+        auto cmp = [&](const char* what, int len, bool edge) {
+            std::vector<uint32_t> a(lanes * 8 * N), b(lanes * 8 * N);
+            hipMemcpy(a.data(), a32, a.size() * 4, hipMemcpyDeviceToHost);
+            hipMemcpy(b.data(), arr, b.size() * 4, hipMemcpyDeviceToHost);
+            int mism = 0;
+            for (size_t i = 0; i < lanes; ++i) {
+                bool eq = true;
+                for (int j = 0; j < 8 * N; ++j) eq &= a[i * 8 * N + j] == b[i * 8 * N + j];
+                if (!eq && mism++ < 3) {
+                    printf("  general-add mismatch thread %zu len %d\n   32: ", i, len);
+                    for (int j = 0; j < 8 * N; ++j) printf("%08x ", a[i * 8 * N + j]);
+                    printf("\n   rr: ");
+                    for (int j = 0; j < 8 * N; ++j) printf("%08x ", b[i * 8 * N + j]);
+                    printf("\n");
+                }
+            }
+            printf("%s, general additions%s%s: len %2d: %d mismatches of %zu threads\n", name, what, edge ? " (edge operands)" : "", len, mism, lanes);
+            bad += mism;
+        };
+        for (int pass = 0; pass < 2; ++pass)
+        for (int len : {0, 1, 2, 3}) {
+            const size_t tab = pass ? 64 : npts;
+            hipLaunchKernelGGL((k_check_add<P, Fp<P, true>, Rr<P>, 1>), dim3(lanes / 256), dim3(256), 0, 0, dp, tab, len, a32, arr);
+            cmp("", len, pass != 0);
+            if constexpr (NR2 != 0) {
+                hipLaunchKernelGGL((k_check_add<P, Fp2H<P, NR2>, Rr2H<P, NR2>, 2>), dim3(lanes / 256), dim3(256), 0, 0, dp, tab, len, a32, arr);
+                cmp(" on Fq2 lane pairs", len, pass != 0);
+            }
+        }
+        hipFree(a32);
+        hipFree(arr);
     }
     if constexpr (NR2 != 0) {
         for (int pass = 0; pass < 2; ++pass)
