@@ -31,7 +31,7 @@
 // Small inputs: a device MSM has a floor of about 0.7 ms (launch chain, bucket reduction, final
 // Horner) whatever its size, while the reference runs a handful of points straight through its
 // inner loop in microseconds (multiexp.tcc:655-661).  Calls with fewer than
-// libff_amd::small_input_threshold() points (default 32; AMDMSM_CPU_BELOW in the environment; 0
+// libff_amd::small_input_threshold() points (default 8; AMDMSM_CPU_BELOW in the environment; 0
 // sends every size to the device) therefore run the CALLER'S OWN libff body -- the reference's
 // generic multi_exp / multi_exp_filter_one_zero, instantiated in the caller's translation unit
 // through a field tag type the specialisations below do not capture.  Nothing of that is compiled
@@ -157,13 +157,14 @@ inline int &endomorphism_mode()
 }
 
 /// Inputs with fewer points than this run the caller's own libff CPU body (see the header comment).
-/// Measured crossover (profiles/r04_profile_sweep.csv): the device's host entry costs 0.7-1.6 ms for
-/// any small n, the reference ~50 us (alt_bn128 G1) to ~200 us (bw6_761) per point on one core.
+/// Measured crossover (profiles/r04_profile_sweep.csv, EPYC 9575F, one core against the device's host
+/// entry): alt_bn128 G1 n = 8: 0.58 ms on the CPU / 0.93 ms on the device, n = 16: 0.99 / 0.81;
+/// alt_bn128 G2 n = 4: 4.1 / 3.6.  The wide curves cross later (bw6_761 G1: near 100 points).
 inline size_t &small_input_threshold()
 {
     static size_t n = [] {
         const char *env = std::getenv("AMDMSM_CPU_BELOW");
-        return env && *env ? (size_t)std::atol(env) : (size_t)32;
+        return env && *env ? (size_t)std::atol(env) : (size_t)8;
     }();
     return n;
 }
