@@ -27,7 +27,10 @@ GROUP_FLAGS = {g: ["-DAMDMSM_HOT_INLINE=1", "-DAMDMSM_BENCH_BOTH=1"] for g in GR
 # (superseded by the reduced-radix loop below, which is built for three)
 # overlap mode (several MSMs in flight: the tail of one under the sort and accumulation of the next, engine.cpp
 # amdmsm_ctx::bulk_stream): the tail kernels get the 128 registers three accumulation waves leave of a SIMD
-GROUP_FLAGS["alt_bn128_g1"] = GROUP_FLAGS["alt_bn128_g1"] + ["-DAMDMSM_OVERLAP_OK=1", "-DAMDMSM_TAIL_WAVES=4"]
+# (round 4: the tail kernels' serial sums run on reduced-radix limbs and want ~195 registers; capped at 128 for the overlap
+# mode -- which stays off by default, it measured slower -- they spilled 292 B per lane: reduction phase 0.327 / 1.108 / 3.19 ms
+# at 2^20 / 2^23 / 2^26 capped against 0.310 / 1.025 / 3.11 uncapped, profiles/r04_experiments.txt.  No cap any more.)
+GROUP_FLAGS["alt_bn128_g1"] = GROUP_FLAGS["alt_bn128_g1"] + ["-DAMDMSM_OVERLAP_OK=1"]
 # wide fields: unconstrained, the kernel takes 256 VGPRs plus 50..125 AGPRs as spill space and
 # runs ONE wave per SIMD; capped at 256 registers (two waves per SIMD, a little scratch) it is
 # 23-25 % faster (bls12_377 G2 2^21: 28.1 -> 22.9 ms, bw6_761 G1 2^21: 43.8 -> 35.0 ms);

@@ -663,7 +663,7 @@ __global__ void __launch_bounds__(SORT_TPB) k_sort_coarse(const int32_t* __restr
                                                           uint32_t* __restrict__ tmp_payload,
                                                           sort_key_t* __restrict__ tmp_key) {
     // tmp_key: the fine part of the bucket index (fb <= 11 bits) -- all the second level needs
-    __shared__ uint32_t hist[1 << SORT_MAX_HB], lstart[1 << SORT_MAX_HB], lcur[1 << SORT_MAX_HB], tmp[SORT_TPB / 64 + 1];
+    __shared__ uint32_t hist[1 << SORT_MAX_HB], lstart[1 << SORT_MAX_HB], tmp[SORT_TPB / 64 + 1];
     __shared__ uint32_t st_payload[SORT_TILE], st_key[SORT_TILE];
     uint32_t* gbase = hist;   // hist[j] is dead once slot j's global base has been reserved
     const uint32_t nbin = 1u << hb;
@@ -673,30 +673,30 @@ __global__ void __launch_bounds__(SORT_TPB) k_sort_coarse(const int32_t* __restr
     for (uint32_t j = threadIdx.x; j < nbin; j += SORT_TPB) hist[j] = 0;
     __syncthreads();
     constexpr int PER = SORT_TILE / SORT_TPB;
-    uint32_t idx[PER], pay[PER];
+    // ONE LDS atomic per entry: the histogram update returns the entry's rank inside its (tile, bin) run, kept in a
+    // register until the run starts are known (a second, returning atomic on a cursor array used to hand the ranks out)
+    uint32_t idx[PER], pay[PER], rank[PER];
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
         const size_t i = tile0 + (size_t)k * SORT_TPB + threadIdx.x;
         const int32_t d = (i < n) ? digits[(size_t)w * stride + i] : 0;
         idx[k] = d ? (uint32_t)(d < 0 ? -d : d) - 1u : 0xffffffffu;
         pay[k] = digit_payload(i, d);
-        if (d) atomicAdd(&hist[idx[k] >> fb], 1u);
+        rank[k] = d ? atomicAdd(&hist[idx[k] >> fb], 1u) : 0u;
     }
     __syncthreads();
     const uint32_t total = block_exclusive_scan(hist, lstart, nbin, tmp);
-    for (uint32_t j = threadIdx.x; j < nbin; j += SORT_TPB) {
-        const uint32_t h = hist[j];
-        lcur[j] = lstart[j];
-        gbase[j] = h ? atomicAdd(&cursor[(size_t)w * nbin + j], h) : 0u;
-    }
-    __syncthreads();
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
         if (idx[k] != 0xffffffffu) {
-            const uint32_t r = atomicAdd(&lcur[idx[k] >> fb], 1u);
+            const uint32_t r = lstart[idx[k] >> fb] + rank[k];
             st_payload[r] = pay[k];
             st_key[r] = idx[k];
         }
+    }
+    for (uint32_t j = threadIdx.x; j < nbin; j += SORT_TPB) {
+        const uint32_t h = hist[j];
+        gbase[j] = h ? atomicAdd(&cursor[(size_t)w * nbin + j], h) : 0u;
     }
     __syncthreads();
     for (uint32_t k = threadIdx.x; k < total; k += SORT_TPB) {
@@ -755,8 +755,34 @@ __global__ void __launch_bounds__(NT) k_sort_fine(const uint32_t* __restrict__ t
     // A bin of several chunks keeps one histogram per chunk (perchunk: room for them behind the staging area), so that
     // pass B needs no second count of each chunk: two LDS atomics and two reads of the key per entry instead of three
     // (the fine pass is bound by them: 6.2 ms of a 2^26-point MSM).
+    if (m <= chunk_cap) {
+        // The bin is one chunk (every bin of a uniformly random input up to ~2^22 points): ONE LDS atomic per entry -- the
+        // histogram update returns the entry's rank inside its bucket, kept in a register (at most chunk_cap / NT = 16 per
+        // thread) until the bucket starts are known -- one read of the key, and the staged chunk IS the bin's list.
+        constexpr int PER = 16;
+        uint32_t fk[PER], rk[PER];
+        for (uint32_t j = threadIdx.x; j < nfine; j += NT) chist[j] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const uint32_t k = threadIdx.x + (uint32_t)q * NT;
+            fk[q] = k < m ? (uint32_t)(key[k] & fmask) : 0u;
+            rk[q] = k < m ? atomicAdd(&chist[fk[q]], 1u) : 0u;
+        }
+        __syncthreads();
+        block_exclusive_scan<NT>(chist, fstart, nfine, tmp);
+        for (uint32_t j = threadIdx.x; j < nfine; j += NT) e[j] = b0 + fstart[j] + chist[j];
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const uint32_t k = threadIdx.x + (uint32_t)q * NT;
+            if (k < m) st_payload[fstart[fk[q]] + rk[q]] = pay[k];
+        }
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < m; k += NT) out[k] = st_payload[k];
+        return;
+    }
     const uint32_t nch = (m + chunk_cap - 1) / chunk_cap;
-    const bool single = m <= chunk_cap;   // the bin is one chunk: pass A's histogram and scan are the chunk's
+    const bool single = false;   // (one-chunk bins took the path above)
     uint32_t* ch = reinterpret_cast<uint32_t*>(st_fine + chunk_cap);   // [nch][nfine]
     const bool split_hist = !single && (size_t)nch * nfine <= perchunk_words;
     if (split_hist) {
