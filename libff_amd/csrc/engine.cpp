@@ -265,14 +265,29 @@ double plan_cost(const group_vtable *vt, size_t n, int c, bool glv) {
 // n: points
 int choose_c(const group_vtable *vt, size_t n, bool glv = false, double *cost_out = nullptr) {
     if (n == 0) return 2;
+    // Small and medium inputs are launch and chain latency, which the model does not describe; the choice there is measured
+    // (profiles/r04_experiments.txt, every group, c = 2 .. 16 at 2^2 .. 2^17 points).  Since the bucket reduction became plain sums
+    // (row / column sums, bit planes: c >= 10) the short Horner of few wide windows wins over few buckets: c = 10 up to 2^10
+    // points (alt_bn128 G2 n = 4: 1.41 ms against 3.19 at the c = 2 the model used to pick, bw6_761 G1 2.1 against 3.4),
+    // c = 13 -- a square 64 x 64 weight matrix -- from there to where c = 16 takes over: 2^15 points for the prime-field groups
+    // under the endomorphism split, 2^17 for Fq2 and 761-bit coordinates, 2^18 without the split (alt_bn128 G1 2^12: 0.49 ms
+    // against 0.61 at c = 8; alt_bn128 G2 2^16: 1.93 against 2.36 at c = 16).  Round 2's rule (c = 8 below 2^16) dated from
+    // the segment kernels.
+    {
+        const bool slow_field = vt->fq_words >= 24 || vt->el_words > vt->fq_words;
+        const size_t n13 = !glv ? ((size_t)1 << 18) : (slow_field ? ((size_t)1 << 17) : ((size_t)1 << 15));
+        int small_c = 0;
+        if (n < 1024) small_c = 10;
+        else if (n < n13) small_c = (vt->fq_words >= 24 && n < ((size_t)1 << 15)) ? 12 : 13;
+        else if (n < 65536) small_c = 16;   // 2^15 points under the split: 0.54 ms against 0.57 at c = 13 and 0.70 at c = 8
+        if (small_c) {
+            if (cost_out) *cost_out = plan_cost(vt, n, small_c, glv);
+            return small_c;
+        }
+    }
     double best = 1e300;
     int best_c = 2;
     for (int c = 2; c <= 22; ++c) {
-        // below 2^16 points everything is launch and chain latency, which the model does not describe:
-        // measured (2^8 .. 2^15, profiles/r02_experiments.txt) c = 8 -- 128 buckets, a window's 64
-        // segments fold inside one wave, no second reduction launch -- beats every c from 9 to 15
-        // (2^14: 0.90 vs 1.02 ms at c = 10), and c = 16 takes over at 2^15 / 2^16
-        if (n < 65536 && c > 8 && c < 16) continue;
         const double cost = plan_cost(vt, n, c, glv);
         if (cost < best) {
             best = cost;

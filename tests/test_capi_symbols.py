@@ -65,6 +65,28 @@ def test_sizes_and_plan_without_gpu(lib):
         assert libff_amd.pippenger_optimal_c(int(n)) == c
 
 
+def test_planner_window_rule_for_small_and_medium_inputs(lib):
+    """The planner's measured window sizes (engine.cpp choose_c, profiles/r04_experiments.txt): c = 10 below 2^10 points,
+    c = 13 (12 for bw6_761 below 2^15) up to 2^15 / 2^17 / 2^18 points depending on group and split, c = 16 beyond, and
+    the configurations BASELINE.json names keep the choices the numbers in DESIGN.md were measured with."""
+    import libff_amd
+
+    def c_of(curve, group, lg, endo=0):
+        p = libff_amd.plan(curve, group, 1 << lg, endomorphism=endo)
+        return p["c"], p["endomorphism"]
+
+    assert c_of(0, 1, 2) == (10, True) and c_of(0, 1, 9) == (10, True)
+    assert c_of(0, 1, 10) == (13, True) and c_of(0, 1, 14) == (13, True)
+    assert c_of(0, 1, 15) == (16, True) and c_of(0, 1, 20) == (16, True)
+    assert c_of(0, 2, 4) == (10, False) and c_of(0, 2, 16) == (13, False) and c_of(0, 2, 18) == (16, False)
+    assert c_of(0, 2, 16, endo=1) == (13, True) and c_of(0, 2, 17, endo=1) == (16, True)
+    assert c_of(2, 1, 12, endo=1) == (12, True) and c_of(2, 1, 16, endo=1) == (13, True)
+    # BASELINE configs: [1] 2^20, the 2^23 shard of [3], 2^26; [2] bls12_377 G1 2^22; [4] shards
+    assert c_of(0, 1, 23) == (19, True) and c_of(0, 1, 26) == (20, False)
+    assert c_of(1, 1, 22) == (17, False)
+    assert c_of(2, 1, 21, endo=1) == (16, True) and c_of(1, 2, 21, endo=1) == (16, True)
+
+
 def test_compute_fails_loudly_without_gpu(lib):
     """No CPU fallback: creating an engine on a GPU-less host must raise."""
     import libff_amd
