@@ -1441,7 +1441,7 @@ AMDMSM_DEV void fixup_compact_block(uint32_t blk, const uint32_t* __restrict__ e
 // blocks [0, fix_blocks): the spans; blocks from fix_blocks on: the folding of aligned blocks inside very long spans
 // (fixup_compact_block below) -- independent work in one launch: an inline span never reaches a folded block's first
 // slot, which only the queue pass that follows reads
-__global__ void __launch_bounds__(64) k_accumulate_fixup(const uint32_t* __restrict__ ends,
+__global__ void __launch_bounds__(64, AMDMSM_TAIL_WAVES) k_accumulate_fixup(const uint32_t* __restrict__ ends,
                                                          uint32_t* __restrict__ part_first,
                                                          const uint32_t* __restrict__ part_last,
                                                          const uint32_t* __restrict__ cont_bucket,
