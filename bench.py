@@ -18,6 +18,12 @@ N > 1   one rank per GPU (started by torch.distributed.run -- by the caller, or 
         points in total each, issued together on two streams per rank), the weak-scaling figure
         (2^20 points per GPU) and the same 2^26 MSM on rank 0 alone.
 
+The driver's record keeps the scalar keys of `config` and `roofline` and drops nested objects, so every figure the metric is
+quoted on is ALSO a scalar key of `config`: ms_per_step_2p26 / value_2p26 / sort_ms_2p26 / accumulate_ms_2p26 / mac_issue_frac_2p26
+(the 2^26 half of the metric), ms_per_step_<leg> / value_<leg> for the R32 bases (the reference profiler's input shape), configs[2],
+the configs[4] shards and totals, the per-rank shards of configs[3] (2^23 / 2^24 / 2^25) and predicted_efficiency_{2,4,8}gpu (whole
+input / (N x (shard + 0.05 ms exchange)): a prediction from one GPU, never a measurement of N).
+
 The JSON line also carries
   roofline      bucket-accumulation kernel (dominant): algorithmic bytes per launch
                 (96 B per alt_bn128 G1 point x points per launch) over its

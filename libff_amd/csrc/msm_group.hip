@@ -1333,6 +1333,9 @@ __global__ void __launch_bounds__(TPB, AMDMSM_ACC_WAVES) k_accumulate(const uint
 #endif
         if (k == bend) {
             // bucket b ends here: it is complete unless its head lies in an earlier lane
+            // (round 4 measured two cheaper forms of this block -- the limbs stored straight from the accumulator registers
+            // with the all-zero record out of line, 160 instead of 230 instructions, and the next end requested before the
+            // stores -- and found no difference on one box, profiles/r04_experiments.txt: the block is not what a boundary costs)
             acc_store(from_prev ? part_first + g * ZZS : bk + (size_t)b * ZZS, acc);
             from_prev = false;
             acc_reset(acc);

@@ -256,6 +256,10 @@ def run_sequences(ch, fq2_nr=0):
     for start in (first_point(ch, fq2_nr), doubling_path(ch, fq2_nr)):
         acc = start
         for _ in range(8):
+            # the record form's mark (msm_group.hip load_xyzz_rec / rec_load_rho): a limb record's last word is the top limb of
+            # ZZZ, and a canonical record is told from it by bits 30 and 31 of that word being different -- so in every state
+            # a bucket can be stored in, that limb must stay below 2^30 in magnitude
+            assert acc["zzz"].top_mag < 2 ** 30, acc["zzz"]
             acc = madd(ch, acc, fq2_nr=fq2_nr)
         last = acc
     return last
