@@ -12,12 +12,12 @@
 //   k_accumulate one lane per S consecutive entries of a window's sorted list (segmented sum
 //                by bucket, fixed work per lane): mixed additions
 //                (multi_exp_add_element_to_bucket_with_signed_digit, multiexp.tcc:45-81) on
-//                reduced-radix limbs (rr.cuh); k_rr_export rewrites the accumulator records as
-//                canonical 32-bit words; k_accumulate_fixup closes the buckets that span lanes
-//   k_reduce_segments / k_sum_butterfly
-//                sum_b (b+1) * B_b (multiexp_accumulate_buckets, multiexp.tcc:90-125)
-//                as L-bucket running sums + a small scalar multiple per segment, folded
-//                64:1 per wave with XOR butterflies
+//                reduced-radix limbs (rr.cuh), records written as limbs; k_accumulate_fixup closes the
+//                buckets that span lanes (its sums, like k_bucket_sums', stay on the limbs: rec_sum)
+//   k_bucket_sums / k_plane_sums / k_window_horner
+//                sum_b (b+1) * B_b (multiexp_accumulate_buckets, multiexp.tcc:90-125) as plain sums: row and
+//                column sums of the weight matrix, bit planes, a short Horner per window (c >= 10;
+//                k_reduce_segments / k_sum_butterfly -- running sums per segment -- below that)
 //   k_horner     high-to-low window combination with c doublings (multiexp.tcc:612-629) on
 //                lane-split field elements (wide.cuh)
 //
@@ -113,8 +113,8 @@ constexpr int AFFW = 2 * EW;          // words per compact affine point
 constexpr int XYZW = 3 * EW;          // words per (X, Y, Z) record
 constexpr int ZZW = 4 * EW;           // words per (X, Y, ZZ, ZZZ) bucket accumulator
 // AMDMSM_ACC_RR: k_accumulate keeps its accumulators on reduced-radix limbs (rr.cuh; an Fq2 element over a pair of
-// lanes as with AMDMSM_ACC_SPLIT) and writes them as they are -- 4 L limbs per component; k_rr_export rewrites every
-// record in place as canonical (X, Y, ZZ, ZZZ) words before any other kernel reads it.  ZZS = words between two
+// lanes as with AMDMSM_ACC_SPLIT) and writes them as they are -- 4 L limbs per component; the kernels that read the
+// records take that form or canonical (X, Y, ZZ, ZZZ) words (load_xyzz_rec / rec_load_rho).  ZZS = words between two
 // records of the bucket / partial arrays (group_vtable::bucket_words).
 #ifndef AMDMSM_ACC_RR
 #define AMDMSM_ACC_RR 0
@@ -994,7 +994,7 @@ struct acc_state {
     bool inf;
 };
 AMDMSM_DEV void acc_reset(acc_state& s) { s.inf = true; }   // the limbs are dead while inf is set
-// the record as it is: this lane's 4 L limbs (all zero: infinity); k_rr_export makes canonical words of it
+// the record as it is: this lane's 4 L limbs (all zero: infinity); its readers convert (load_xyzz_rec / rec_load_rho)
 AMDMSM_DEV void acc_store(uint32_t* q, const acc_state& s) {
     uint4* q4 = reinterpret_cast<uint4*>(q + (GP::DEG == 2 && (threadIdx.x & 1u) ? 4 * RRL : 0));
     if (__builtin_expect(s.inf, 0)) {   // a bucket whose points cancelled (or a piece with infinite bases only)

@@ -16,9 +16,9 @@
 //   * the Montgomery radix is rho = 2^(B L) >= 2^(32 N + 5): p / rho <= 2^-7, so a product of
 //     operands bounded by A p and A' p lies in (-e p, (1 + e) p) with e = A A' p / rho -- values
 //     contract, nothing in the loop ever needs a conditional subtraction.
-// Nothing is kept in this form between kernels: k_rr_export turns k_accumulate's records back into
-// canonical 32-bit Montgomery residues (R = 2^(32N), fp.cuh) before any other kernel reads them,
-// the other users convert in registers.  Contents: limbs and constants, multiply chains, products /
+// Between kernels the form lives only in k_accumulate's bucket / partial records, which the fix-up kernels and
+// k_bucket_sums read as they are (msm_group.hip rec_load_rho) and sum on the limbs (xyzz_add_rho below); everything
+// further down the pipeline sees canonical 32-bit Montgomery residues (R = 2^(32N), fp.cuh); the other users convert in registers.  Contents: limbs and constants, multiply chains, products /
 // squaring / linear operations, conversions and exact residue tests, the element interface re_* (Fq per
 // lane, Fq2 over a lane pair), the XYZZ mixed addition of the bucket loop, export, Jacobian doubling /
 // mixed addition.
@@ -843,7 +843,7 @@ AMDMSM_DEV void xyzz_add_rho(XyzzRr<E>& a, bool& a_inf, const XyzzRr<E>& b, bool
 }
 
 // r = a * 2^E / rho: the product scan with a one-limb second factor -- one multiply per column in the multiplication
-// half instead of up to L (k_rr_export runs four of these per record)
+// half instead of up to L (the export of a sum runs four of these)
 template <class P, int E, int K>
 AMDMSM_DEV void rr_mulp2_column(int64_t& acc, int32_t* m, int32_t* t, const int32_t* a) {
     constexpr int L = rr_shape<P>::L;

@@ -210,7 +210,9 @@ def _closed_form_scalar(port, curve, scalars_mont, first):
 
 @pytest.mark.parametrize("name,curve,group,log2n", [("alt_bn128_g1", 0, 1, 20), ("alt_bn128_g1", 0, 1, 22),
                                                      ("bls12_377_g1", 1, 1, 18), ("bw6_761_g1", 2, 1, 16),
-                                                     ("bls12_377_g2", 1, 2, 16)])
+                                                     ("bls12_377_g2", 1, 2, 16), ("alt_bn128_g2", 0, 2, 18),
+                                                     ("bls12_381_g1", 3, 1, 18), ("bls12_381_g2", 3, 2, 16),
+                                                     ("bw6_761_g2", 2, 2, 15)])
 def test_full_size_closed_form_and_sharding(engine, port, name, curve, group, log2n):
     """BASELINE configs at full size (2^20 alt_bn128 G1): the reference's own test pattern
     (test_multiexp.cpp:205-256) -- bases [i+1]G so that the expected value is the closed

@@ -269,7 +269,7 @@ def run_sequences(ch, fq2_nr=0):
 def test_bucket_loop_bounds_fq(name):
     ch = Checker(Shape(name))
     steady = run_sequences(ch)
-    assert steady["x"].val < 16 and steady["y"].val < 4, steady     # what k_rr_export and the next filter rely on
+    assert steady["x"].val < 16 and steady["y"].val < 4, steady     # what the export of a record and the next filter rely on
     assert ch.worst_column < 2 ** 63
     # export: x 2^(32N) / rho must land in (-p, 2p): |x| below 2^D p in every state
     for start in (first_point(ch), doubling_path(ch)):
