@@ -1051,10 +1051,14 @@ constexpr uint32_t NO_BUCKET = 0xffffffffu;
 
 // A record of the bucket / partial arrays (ZZS words) comes in two forms:
 //   * as k_accumulate wrote it (AMDMSM_ACC_RR): 4 L reduced-radix limbs per component, all zero = infinity;
-//   * canonical (X, Y, ZZ, ZZZ) words at the start of the record, as the fix-up kernels write their sums, with a mark
+//   * canonical (X, Y, ZZ, ZZZ) words at the start of the record (the 32-bit fallback of the fix-up kernels), with a mark
 //     in the record's last word -- a word the canonical layout leaves free (ZZS > ZZW) and that in the limb form is the
 //     top limb of ZZZ: a product's output or the constant one, far below 2^30 in magnitude, so that its bits 30 and 31
-//     are equal there.
+//     are equal there;
+//   * a sum of the fix-up kernels on limbs (rec_sum_store): the limb layout with ALL FOUR coordinates carrying the factor
+//     rho (k_accumulate's zz / zzz carry rho 2^D), marked by bit 31 of limb 0 of ZZ -- limbs 0 .. L-2 of ZZ are a
+//     product's output in every state, in [0, 2^B).  Three quarters of the buckets of a 2^20-point MSM span two lanes
+//     and are written this way: their readers need no conversion at all, and the writer no export.
 // Every reader takes either (load_xyzz_rec): the limb form is turned into canonical words in registers -- one product by a
 // power of two and one exact normalisation per coordinate (rr_export_component) -- which used to be a pass of its own over
 // all records, read or not (k_rr_export: a memory round trip of 272 B per record, 3 % of a 2^20-point MSM).
@@ -1079,6 +1083,8 @@ AMDMSM_DEV void load_xyzz_rec(Xyzz<T>& p, const uint32_t* q) {
         w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
     }
     constexpr int D = rr_shape<FQ>::D;
+    const bool rho = (w[2 * RRL] >> 31) != 0;   // a fix-up kernel's sum: zz, zzz with the factor rho
+    w[2 * RRL] &= 0x7fffffffu;
     Rr<FQ> a;
     // (zero limbs give zero words: an all-zero record reads as ZZ == 0, infinity; a zero component of a finite Fq2
     // point stays zero)
@@ -1090,10 +1096,12 @@ AMDMSM_DEV void load_xyzz_rec(Xyzz<T>& p, const uint32_t* q) {
     rr_export_component<FQ, 0>(lane_words(p.y), a);
 #pragma unroll
     for (int k = 0; k < RRL; ++k) a.v[k] = (int32_t)w[2 * RRL + k];
-    rr_export_component<FQ, D>(lane_words(p.zz), a);
+    if (rho) rr_export_component<FQ, 0>(lane_words(p.zz), a);
+    else rr_export_component<FQ, D>(lane_words(p.zz), a);
 #pragma unroll
     for (int k = 0; k < RRL; ++k) a.v[k] = (int32_t)w[3 * RRL + k];
-    rr_export_component<FQ, D>(lane_words(p.zzz), a);
+    if (rho) rr_export_component<FQ, 0>(lane_words(p.zzz), a);
+    else rr_export_component<FQ, D>(lane_words(p.zzz), a);
 }
 template <class T>
 AMDMSM_DEV void store_xyzz_rec(uint32_t* q, const Xyzz<T>& p) {
@@ -1150,7 +1158,26 @@ AMDMSM_DEV void rec_load_rho(XyzzRr<ERR>& p, bool& inf, const uint32_t* q) {
     }
     // k_accumulate writes infinity as an all-zero record; the zz of a finite point is never zero mod p, let alone on limbs
     inf = re_all<ERR>(any == 0);
-    xyzz_rec_to_rho(p);
+    // a fix-up kernel's sum (rec_sum_store): every coordinate has the factor rho already
+    const bool rho = re_limb(p.zz, 0) < 0;   // bit 31 of limb 0 of ZZ, which is never negative
+    if (rho) re_limb(p.zz, 0) &= 0x7fffffff;
+    else xyzz_rec_to_rho(p);
+}
+// the sum as a record of the third form (or an all-zero record: infinity)
+AMDMSM_DEV void rec_sum_store(uint32_t* q, const rec_sum& s) {
+    uint4* q4 = reinterpret_cast<uint4*>(q + (GP::DEG == 2 && (threadIdx.x & 1u) ? 4 * RRL : 0));
+    uint32_t w[4 * RRL];
+    const uint32_t keep = s.inf ? 0u : 0xffffffffu;
+#pragma unroll
+    for (int i = 0; i < RRL; ++i) {
+        w[i] = (uint32_t)re_limb(s.a.x, i) & keep;
+        w[RRL + i] = (uint32_t)re_limb(s.a.y, i) & keep;
+        w[2 * RRL + i] = (uint32_t)re_limb(s.a.zz, i) & keep;
+        w[3 * RRL + i] = (uint32_t)re_limb(s.a.zzz, i) & keep;
+    }
+    w[2 * RRL] |= 0x80000000u & keep;
+#pragma unroll
+    for (int i = 0; i < RRL; ++i) q4[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
 }
 AMDMSM_DEV void rec_sum_add(rec_sum& s, const uint32_t* q) {
     XyzzRr<ERR> b;
@@ -1196,6 +1223,7 @@ AMDMSM_DEV void rec_sum_add(rec_sum& s, const uint32_t* q) {
     xyzz_add(s.a, s.a, x);
 }
 AMDMSM_DEV void rec_sum_get(Xyzz<ER>& out, const rec_sum& s) { out = s.a; }
+AMDMSM_DEV void rec_sum_store(uint32_t* q, const rec_sum& s) { store_xyzz_rec(q, s.a); }
 AMDMSM_DEV void wave_group_sum_r(Jac<ER>& p, uint32_t G);
 AMDMSM_DEV void rec_sum_fold(rec_sum& s, uint32_t G) {
     Jac<ER> j;
@@ -1500,9 +1528,7 @@ __global__ void __launch_bounds__(64, AMDMSM_TAIL_WAVES) k_accumulate_fixup(cons
             if (done >= 3) __builtin_amdgcn_s_setprio(0);
         }
     }
-    Xyzz<ER> acc;
-    rec_sum_get(acc, sum);
-    store_xyzz_rec(buckets + (w * B + b) * ZZS, acc);
+    rec_sum_store(buckets + (w * B + b) * ZZS, sum);
 }
 
 // A bucket that spans thousands of lanes (one scalar value repeated across much of the input)
@@ -1530,9 +1556,7 @@ AMDMSM_DEV void fixup_compact_block(uint32_t blk, const uint32_t* __restrict__ e
     rec_sum_init(sum);
     for (uint32_t u = first + lane; u <= last; u += RED_FOLD) rec_sum_add(sum, part_first + (w * T + u) * ZZS);
     rec_sum_fold(sum, RED_FOLD);
-    Xyzz<ER> acc;
-    rec_sum_get(acc, sum);
-    if (lane == 0) store_xyzz_rec(part_first + (w * T + first) * ZZS, acc);
+    if (lane == 0) rec_sum_store(part_first + (w * T + first) * ZZS, sum);
 }
 
 // G lanes per queued bucket (G = 64 for the long queue, MID_G for the mid queue): the lanes
@@ -1587,9 +1611,7 @@ __global__ void __launch_bounds__(64, AMDMSM_TAIL_WAVES) k_accumulate_fixup_queu
             }
         }
         rec_sum_fold(sum, G);
-        Xyzz<ER> acc;
-        rec_sum_get(acc, sum);
-        if (live && lane == 0) store_xyzz_rec(buckets + (w * B + b) * ZZS, acc);
+        if (live && lane == 0) rec_sum_store(buckets + (w * B + b) * ZZS, sum);
     }
 }
 
