@@ -81,8 +81,8 @@ FR_MODULUS = {
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--log2n", type=int, default=int(os.environ.get("AMDMSM_BENCH_LOG2N", "0")),
                     help="points of the `value` workload: per GPU at N = 1 (default 20), in TOTAL at N > 1 (default 26)")
     ap.add_argument("--curve", default="alt_bn128", choices=sorted(CURVES))
