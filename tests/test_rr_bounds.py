@@ -429,6 +429,7 @@ def general_add_states(ch, fq2_nr=0):
             assert acc[k].val <= 2 ** s.D, (k, acc[k])
         # rec_sum_store marks a sum's record in bit 31 of limb 0 of ZZ: that limb is a product's output, never negative
         assert 0 <= acc["zz"].lo and acc["zz"].hi < 2 ** s.B, acc["zz"]
+        assert acc["zzz"].top_mag < 2 ** 30, acc["zzz"]   # ... and its last word must not read as the canonical form's mark
     assert 0 <= rec["zz"].lo and rec["zz"].hi < 2 ** s.B, rec["zz"]   # and so is it in every record k_accumulate writes
     return acc
 
