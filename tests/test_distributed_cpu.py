@@ -53,6 +53,13 @@ def _worker(rank, world, port_no, curve, group, n, q):
             return port.group_op(curve, group, 4, acc)
 
         res = sharded_multi_exp(local_msm, combine)
+        # the form ShardedMsm uses: one all_gather_into_tensor into a buffer the caller owns (no per-step allocation)
+        from libff_amd.distributed import all_gather_partials
+
+        mine = local_msm()
+        buf = torch.full((world, mine.numel()), -1, dtype=mine.dtype)
+        got = all_gather_partials(mine, out=buf)
+        assert got.data_ptr() == buf.data_ptr() and (buf[rank] == mine).all() and (combine(buf) == res).all()
         q.put((rank, lo, hi, res.tolist()))
     finally:
         dist.destroy_process_group()
