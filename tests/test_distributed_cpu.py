@@ -65,7 +65,7 @@ def _worker(rank, world, port_no, curve, group, n, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,curve,group,n", [(2, 0, 1, 301), (3, 1, 1, 100), (2, 2, 1, 1)])
+@pytest.mark.parametrize("world,curve,group,n", [(2, 0, 1, 301), (3, 1, 1, 100), (2, 2, 1, 1), (8, 0, 1, 203)])   # 8: the node the bench targets
 def test_sharded_msm_gloo(port, world, curve, group, n):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
