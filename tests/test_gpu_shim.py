@@ -20,6 +20,7 @@ def test_template_shim_with_real_libff_types():
     print(r.stdout[-3000:])
     print(r.stderr[-2000:])
     assert r.returncode == 0 and "SHIM CHECK PASSED" in r.stdout
+    assert r.stdout.count("small-input routing n=1..64: ok") == 3   # both routes of the small-input threshold, three groups
     # the 2^20-point call with chunks = 16 (one MSM, not 16) and the registered-bases call ran
     assert "chunks=16" in r.stdout and "filter_one_zero ok" in r.stdout
 
@@ -31,7 +32,7 @@ def test_template_shim_multi_device_route():
     through amdmsm_multi_exp_multi (multiexp.tcc:655-687 with chunk = context)."""
     if not os.path.exists(BIN):
         pytest.skip("oracle/_ref/shim_check not built (needs the reference sources at build time)")
-    env = dict(os.environ, AMDMSM_DEVICES="0,0", SHIM_CHECK_MIN_SPLIT="100", SHIM_CHECK_SKIP_LARGE="1")
+    env = dict(os.environ, AMDMSM_DEVICES="0,0", SHIM_CHECK_MIN_SPLIT="100", SHIM_CHECK_SKIP_LARGE="1", SHIM_CHECK_SKIP_SMALL="1")
     r = subprocess.run([BIN], capture_output=True, text=True, timeout=900, env=env)
     print(r.stdout[-3000:])
     print(r.stderr[-2000:])
@@ -44,7 +45,7 @@ def test_template_shim_with_endomorphism_permitted():
     split their scalars too (their bases are libff group elements: in the order-r subgroup)."""
     if not os.path.exists(BIN):
         pytest.skip("oracle/_ref/shim_check not built (needs the reference sources at build time)")
-    env = dict(os.environ, SHIM_CHECK_ENDOMORPHISM="1", SHIM_CHECK_SKIP_LARGE="1")
+    env = dict(os.environ, SHIM_CHECK_ENDOMORPHISM="1", SHIM_CHECK_SKIP_LARGE="1", SHIM_CHECK_SKIP_SMALL="1")
     r = subprocess.run([BIN], capture_output=True, text=True, timeout=900, env=env)
     print(r.stdout[-3000:])
     print(r.stderr[-2000:])
